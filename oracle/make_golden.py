@@ -1,0 +1,362 @@
+"""Generate golden vectors by running the REFERENCE's own modules (imported from
+/root/reference, which exists only in the build container) with eps injected from the
+build's RNG spec.  Output: tests/golden/*.npz (data only: inputs are regenerated from seeds,
+expected outputs are stored).  Run:  python oracle/make_golden.py
+
+Test infrastructure; never shipped in the product path and never run on the GPU box.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import oracle as O  # noqa: E402
+
+
+def import_reference():
+    # in-process empty stubs for packages the reference imports but never uses on this path
+    for m in ["torchvision", "torchvision.transforms", "skimage", "skimage.metrics"]:
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["skimage.metrics"].peak_signal_noise_ratio = None
+    sys.path.insert(0, REF)
+    import BayTorch.freq_to_bayes as f2b
+    import BayTorch.modules.module as vimod
+    import models
+    import models.skip  # noqa: F401
+    mskip = sys.modules['models.skip']   # models/__init__ rebinds the name `skip` to the function
+    import radon.radon as radon
+    import utils.bayesian_utils as bu
+    import utils.common_utils as cu
+    return dict(f2b=f2b, vimod=vimod, models=models, mskip=mskip, radon=radon, bu=bu, cu=cu)
+
+
+R = import_reference()
+torch.set_num_threads(8)
+
+
+class EpsInjector:
+    """Replaces VIModule.rsample (modules/module.py:82-85) by a version that consumes eps
+    produced by the build's RNG spec, in call order (weight then bias per layer)."""
+
+    def __init__(self):
+        self.queue = []
+        self.orig = R["vimod"].VIModule.rsample
+
+    def __enter__(self):
+        q = self.queue
+
+        def rsample(mu, sigma):
+            e = q.pop(0)
+            assert e.shape == mu.shape, (e.shape, mu.shape)
+            return mu + e * sigma
+        R["vimod"].VIModule.rsample = staticmethod(rsample)
+        return self
+
+    def __exit__(self, *a):
+        R["vimod"].VIModule.rsample = self.orig
+
+    def load(self, layers, seed, step, sample):
+        self.queue.clear()
+        for lid, m in enumerate(layers):
+            self.queue.append(torch.from_numpy(O.eps(seed, step, sample, lid, 0, m.W_mu.numel()).reshape(tuple(m.W_mu.shape))))
+            self.queue.append(torch.from_numpy(O.eps(seed, step, sample, lid, 1, m.bias_mu.numel())))
+
+
+def vi_layers(net):
+    return [m for m in net.modules() if hasattr(m, "W_mu")]
+
+
+def bn_layers(net):
+    return [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+
+
+def load_flat(net, mu, rho, bnp, conv_tbl, bn_tbl):
+    with torch.no_grad():
+        for m, row in zip(vi_layers(net), conv_tbl):
+            cin, cout, k, stride, w_off, b_off = [int(v) for v in row]
+            assert tuple(m.W_mu.shape) == (cout, cin, k, k), (tuple(m.W_mu.shape), row)
+            n = cout * cin * k * k
+            m.W_mu.copy_(torch.from_numpy(mu[w_off:w_off + n].reshape(cout, cin, k, k)))
+            m.W_rho.copy_(torch.from_numpy(rho[w_off:w_off + n].reshape(cout, cin, k, k)))
+            m.bias_mu.copy_(torch.from_numpy(mu[b_off:b_off + cout]))
+            m.bias_rho.copy_(torch.from_numpy(rho[b_off:b_off + cout]))
+        for m, (c, off) in zip(bn_layers(net), bn_tbl):
+            c, off = int(c), int(off)
+            assert m.num_features == c
+            m.weight.copy_(torch.from_numpy(bnp[off:off + c]))
+            m.bias.copy_(torch.from_numpy(bnp[off + c:off + 2 * c]))
+
+
+def flat_grads(net, conv_tbl, bn_tbl, n_vi, n_bnp):
+    dmu = np.zeros(n_vi, np.float64); drho = np.zeros(n_vi, np.float64); dbn = np.zeros(n_bnp, np.float64)
+    for m, row in zip(vi_layers(net), conv_tbl):
+        cin, cout, k, stride, w_off, b_off = [int(v) for v in row]
+        n = cout * cin * k * k
+        dmu[w_off:w_off + n] = m.W_mu.grad.numpy().ravel(); drho[w_off:w_off + n] = m.W_rho.grad.numpy().ravel()
+        dmu[b_off:b_off + cout] = m.bias_mu.grad.numpy(); drho[b_off:b_off + cout] = m.bias_rho.grad.numpy()
+    for m, (c, off) in zip(bn_layers(net), bn_tbl):
+        c, off = int(c), int(off)
+        dbn[off:off + c] = m.weight.grad.numpy(); dbn[off + c:off + 2 * c] = m.bias.grad.numpy()
+    return dmu, drho, dbn
+
+
+def build_ref_net(onet, prior_sigma_raw):
+    """get_net(...)+MeanFieldVI exactly as bayesian_optimization.py:1318-1342 but with the
+    channel lists of `onet` (so small nets can be pinned too)."""
+    n = onet.n_scales
+    net = R["mskip"].skip(onet.input_depth, onet.n_out,
+                          num_channels_down=[onet.nd[i] for i in range(n)],
+                          num_channels_up=[onet.nu[i] for i in range(n)],
+                          num_channels_skip=[onet.ns[i] for i in range(n)],
+                          upsample_mode='bilinear', downsample_mode='stride',
+                          need_sigmoid=False, need_bias=True, pad='reflection', act_fun='LeakyReLU',
+                          dropout_mode_down='None', dropout_mode_up='None', dropout_mode_skip='None', dropout_mode_output='None')
+    net = R["f2b"].MeanFieldVI(net, prior={'mu': 0.0, 'sigma': prior_sigma_raw}, replace_layers='all', reparam='')
+    return net
+
+
+def test_params(onet, seed):
+    mu, rho, bnp = O.init_params(onet, seed)
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    g = O.normal_fill(seed, 2, 7, 0, 0, n_bnp)
+    for c, off in bn:     # non-trivial affine: gamma = 1 + 0.1 n, beta = 0.1 n
+        bnp[off:off + c] = 1.0 + 0.1 * g[off:off + c]
+        bnp[off + c:off + 2 * c] = 0.1 * g[off + c:off + 2 * c]
+    return mu, rho, bnp
+
+
+def strided(a, n=4096):
+    a = np.asarray(a).ravel()
+    step = max(1, a.size // n)
+    return a[::step][:n].copy()
+
+
+DEN = dict(temp=5.656911698337764e-07, sigma=1.4616642493692077e-05)   # test_configs/mfvi_den.json:5,9
+SR = dict(temp=4.381719802264805e-07, sigma=4.9e-08)                   # test_configs/mfvi_sr.json
+CT = dict(temp=2.2e-10, sigma=1.7e-7)                                  # test_configs/mfvi_ct.json
+
+
+def golden_net(name, onet, seed, K, task="den", full_arrays=True, dtype=torch.float32, save=True):
+    cfg = dict(den=DEN, sr=SR, ct=CT)[task]
+    temp = cfg["temp"]; prior_raw = float(np.sqrt(temp) * cfg["sigma"])
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    mu, rho, bnp = test_params(onet, seed)
+    net = build_ref_net(onet, prior_raw)
+    load_flat(net, mu, rho, bnp, conv, bn)
+    net = net.to(dtype)      # float64 run of the same reference code = noise-free anchor for the gradients
+    layers = vi_layers(net)
+    H, W = onet.H, onet.W
+    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, onet.input_depth * H * W)).reshape(1, onet.input_depth, H, W)
+    img = O.phantom(H, W, seed); tgt = O.noisy(img, 0.1, seed)
+    zt = torch.from_numpy(z).to(dtype)
+    res = {}
+    theta = None
+    if task == "ct":
+        theta = torch.arange(0, 180., step=4.)
+        fr = R["radon"].FastRadonTransform((1, 1, H, W), theta)
+        sino_t = fr(torch.from_numpy(img)[None, None]).detach()
+        res["sino_target"] = sino_t.numpy()[0, 0]
+    net.zero_grad()
+    outs = []; nll_sum = 0.0
+    with EpsInjector() as inj:
+        for k in range(K):
+            inj.load(layers, seed, 3, k)
+            inj.queue[:] = [e.to(dtype) for e in inj.queue]
+            out = net(zt)
+            if task == "den":
+                nll = R["bu"].gaussian_nll(out[:, :1], out[:, 1:], torch.from_numpy(tgt)[None, None].to(dtype))
+            elif task == "sr":
+                lr_t = torch.from_numpy(np.ascontiguousarray(tgt[::4, ::4]))[None, None]
+                out_lr = torch.nn.functional.interpolate(out, scale_factor=0.25, mode='nearest', recompute_scale_factor=False)
+                nll = R["bu"].gaussian_nll(out_lr[:, :1], out_lr[:, 1:], lr_t)
+            else:
+                nll = torch.nn.functional.mse_loss(fr(out), sino_t)
+            (nll / K).backward()
+            nll_sum += float(nll) / K
+            outs.append(out.detach().numpy()[0].copy())
+        kl = net.kl()
+        (temp * kl).backward()
+    per_layer_kl = np.array([float(m._kl) for m in layers], np.float64)
+    dmu, drho, dbn = flat_grads(net, conv, bn, n_vi, n_bnp)
+    res.update(dict(seed=seed, K=K, step=3, temp=temp, prior_sigma=np.float32(prior_raw + 1e-6), H=H, W=W,
+                    nll=nll_sum, kl=float(kl), loss=nll_sum + temp * float(kl), per_layer_kl=per_layer_kl,
+                    out=np.stack(outs)))
+    if full_arrays:
+        res.update(dmu=dmu, drho=drho, dbn=dbn)
+    else:
+        res.update(dmu_s=strided(dmu), drho_s=strided(drho), dbn=dbn,
+                   dmu_layer_norm=np.array([np.linalg.norm(dmu[int(r[4]):int(r[5]) + int(r[1])]) for r in conv]),
+                   drho_layer_norm=np.array([np.linalg.norm(drho[int(r[4]):int(r[5]) + int(r[1])]) for r in conv]),
+                   dmu_sum=float(dmu.astype(np.float64).sum()), drho_sum=float(drho.astype(np.float64).sum()))
+    # eval anchor: RT layers in eval (w = mu), BN still in training mode -> RNG-free forward
+    for m in layers:
+        m.training = False
+    with torch.no_grad():
+        res["out_eval"] = net(zt).numpy()[0]
+    for m in layers:
+        m.training = True
+    res["state_dict_keys"] = np.array(list(net.state_dict().keys()))
+    res["layer_names"] = np.array([n for n, m in net.named_modules() if hasattr(m, "W_mu")])
+    if not save:
+        return res
+    if name.startswith("full"):
+        r64 = golden_net(name, onet, seed, K, task, full_arrays=False, dtype=torch.float64, save=False)
+        for kname in ("dmu_s", "drho_s", "dbn", "dmu_layer_norm", "drho_layer_norm", "out", "nll"):
+            res[kname + "_f64"] = np.asarray(r64[kname], np.float64)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **res)
+    print(name, "nll", nll_sum, "kl", float(kl), "out", res["out"].shape, "|dmu|", np.linalg.norm(dmu), "|drho|", np.linalg.norm(drho))
+
+
+def golden_traj(name, onet, seed, K, steps, lr=1e-3):
+    """N optimizer steps of the reference loop (bayesian_optimization.py:1360-1372) with torch AdamW."""
+    temp = DEN["temp"]; prior_raw = float(np.sqrt(temp) * DEN["sigma"])
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    mu, rho, bnp = test_params(onet, seed)
+    net = build_ref_net(onet, prior_raw); load_flat(net, mu, rho, bnp, conv, bn)
+    layers = vi_layers(net)
+    H, W = onet.H, onet.W
+    z0 = (0.1 * O.uniform_fill(seed, 0, 0, 0, onet.input_depth * H * W)).reshape(1, onet.input_depth, H, W)
+    tgt = torch.from_numpy(O.noisy(O.phantom(H, W, seed), 0.1, seed))[None, None]
+    opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=0)
+    losses, nlls, kls = [], [], []
+    with EpsInjector() as inj:
+        for it in range(steps):
+            opt.zero_grad()
+            zn = O.normal_fill(seed, 1, 0, 0, it, z0.size).reshape(z0.shape)      # DOMAIN_INPUT, step = it
+            zt = torch.from_numpy(z0 + 0.1 * zn)
+            nll_sum = 0.0
+            for k in range(K):
+                inj.load(layers, seed, it, k)
+                out = net(zt)
+                nll = R["bu"].gaussian_nll(out[:, :1], out[:, 1:], tgt)
+                (nll / K).backward(); nll_sum += float(nll) / K
+            kl = net.kl(); (temp * kl).backward()
+            opt.step()
+            losses.append(nll_sum + temp * float(kl)); nlls.append(nll_sum); kls.append(float(kl))
+    # final params
+    fmu = np.zeros(n_vi, np.float32); frho = np.zeros(n_vi, np.float32); fbn = np.zeros(n_bnp, np.float32)
+    for m, row in zip(layers, conv):
+        cin, cout, k, stride, w_off, b_off = [int(v) for v in row]; n = cout * cin * k * k
+        fmu[w_off:w_off + n] = m.W_mu.detach().numpy().ravel(); frho[w_off:w_off + n] = m.W_rho.detach().numpy().ravel()
+        fmu[b_off:b_off + cout] = m.bias_mu.detach().numpy(); frho[b_off:b_off + cout] = m.bias_rho.detach().numpy()
+    for m, (c, off) in zip(bn_layers(net), bn):
+        c, off = int(c), int(off)
+        fbn[off:off + c] = m.weight.detach().numpy(); fbn[off + c:off + 2 * c] = m.bias.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, K=K, steps=steps, lr=lr, temp=temp,
+                        prior_sigma=np.float32(prior_raw + 1e-6), H=H, W=W,
+                        loss=np.array(losses), nll=np.array(nlls), kl=np.array(kls), mu=fmu, rho=frho, bn=fbn)
+    print(name, "loss", losses)
+
+
+def golden_layers():
+    """Single Conv2dRT (ReflectionPad2d + conv, models/common.py:100-135) fwd/bwd with injected eps."""
+    from models.common import conv as ref_conv
+    cases = [(16, 4, 1, 1, 12, 12), (16, 16, 3, 2, 16, 16), (16, 16, 3, 1, 10, 14), (36, 16, 3, 1, 8, 8),
+             (8, 32, 3, 2, 12, 20), (32, 2, 1, 1, 6, 6), (132, 8, 3, 1, 8, 8)]
+    res = {}
+    for ci, (cin, cout, k, stride, H, W) in enumerate(cases):
+        seq = ref_conv(cin, cout, k, stride, bias=True, pad='reflection')
+        net = R["f2b"].MeanFieldVI(seq, prior={'mu': 0.0, 'sigma': 0.1}, replace_layers='all', reparam='')
+        m = vi_layers(net)[0]
+        seed = 100 + ci
+        nw = cout * cin * k * k
+        mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+        with torch.no_grad():
+            m.W_mu.copy_(torch.from_numpy(mu[:nw].reshape(cout, cin, k, k))); m.W_rho.copy_(torch.from_numpy(rho[:nw].reshape(cout, cin, k, k)))
+            m.bias_mu.copy_(torch.from_numpy(mu[nw:])); m.bias_rho.copy_(torch.from_numpy(rho[nw:]))
+        x = torch.from_numpy(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(1, cin, H, W)).requires_grad_(True)
+        with EpsInjector() as inj:
+            inj.load([m], seed, 5, 2)
+            y = net(x)
+        dy = torch.from_numpy(O.normal_fill(seed, 2, 3, 0, 0, y.numel()).reshape(y.shape))
+        y.backward(dy)
+        res[f"case{ci}_shape"] = np.array([cin, cout, k, stride, H, W])
+        res[f"case{ci}_y"] = y.detach().numpy()[0]
+        res[f"case{ci}_dx"] = x.grad.numpy()[0]
+        res[f"case{ci}_dWmu"] = m.W_mu.grad.numpy(); res[f"case{ci}_dWrho"] = m.W_rho.grad.numpy()
+        res[f"case{ci}_dbmu"] = m.bias_mu.grad.numpy(); res[f"case{ci}_dbrho"] = m.bias_rho.grad.numpy()
+    res["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(GOLD, "layers.npz"), **res)
+    print("layers ok")
+
+
+def golden_micro():
+    res = {}
+    # BN train-mode N=1 (models/common.py:96-97) + LeakyReLU(0.2) + Upsample bilinear x2 (models/skip.py:102)
+    x = O.normal_fill(7, 2, 0, 0, 0, 6 * 10 * 12).reshape(1, 6, 10, 12) * 1.7 + 0.4
+    g = 1 + 0.1 * O.normal_fill(7, 2, 1, 0, 0, 6); b = 0.1 * O.normal_fill(7, 2, 2, 0, 0, 6)
+    bnm = R["models"].skip.__globals__["bn"](6)
+    with torch.no_grad():
+        bnm.weight.copy_(torch.from_numpy(g)); bnm.bias.copy_(torch.from_numpy(b))
+    xt = torch.from_numpy(x.copy()).requires_grad_(True)
+    act = R["models"].skip.__globals__["act"]('LeakyReLU')
+    up = torch.nn.Upsample(scale_factor=2, mode='bilinear')
+    y = up(act(bnm(xt)))
+    dy = torch.from_numpy(O.normal_fill(7, 2, 3, 0, 0, y.numel()).reshape(y.shape))
+    y.backward(dy)
+    res.update(bn_y=y.detach().numpy()[0], bn_dx=xt.grad.numpy()[0], bn_dgamma=bnm.weight.grad.numpy(), bn_dbeta=bnm.bias.grad.numpy())
+    # gaussian_nll (utils/bayesian_utils.py:29-32) incl. clamped entries
+    o = O.normal_fill(8, 2, 0, 0, 0, 2 * 32 * 32).reshape(1, 2, 32, 32).copy()
+    o[0, 1, 0, :4] = [25.0, -25.0, 20.0, -20.0]
+    t = O.uniform_fill(8, 1, 0, 0, 32 * 32).reshape(1, 1, 32, 32)
+    ot = torch.from_numpy(o).requires_grad_(True)
+    nll = R["bu"].gaussian_nll(ot[:, :1], ot[:, 1:], torch.from_numpy(t)); nll.backward()
+    res.update(nll=float(nll), nll_dout=ot.grad.numpy()[0])
+    # PSNR / SSIM (utils/common_utils.py:297-353)
+    a = O.phantom(48, 40, 3); bb = O.noisy(a, 0.1, 3)
+    res.update(psnr=R["cu"].peak_signal_noise_ratio(torch.from_numpy(a)[None, None], torch.from_numpy(bb)[None, None]),
+               ssim=R["cu"].structural_similarity(torch.from_numpy(a)[None, None], torch.from_numpy(bb)[None, None]))
+    # get_noise stats are not pinned (torch RNG); KL closed form (modules/module.py:64-80)
+    lay = R["vimod"].VIModule(None, (5, 7), (5,), prior={'mu': 0.0, 'sigma': 0.05})
+    mu = 0.1 * O.normal_fill(9, 2, 0, 0, 0, 40); rho = -3 + 0.5 * O.normal_fill(9, 2, 1, 0, 0, 40)
+    with torch.no_grad():
+        lay.W_mu.copy_(torch.from_numpy(mu[:35].reshape(5, 7))); lay.W_rho.copy_(torch.from_numpy(rho[:35].reshape(5, 7)))
+        lay.bias_mu.copy_(torch.from_numpy(mu[35:])); lay.bias_rho.copy_(torch.from_numpy(rho[35:]))
+    klv = lay._kl; klv.backward()
+    res.update(kl=float(klv), kl_dmu=np.concatenate([lay.W_mu.grad.numpy().ravel(), lay.bias_mu.grad.numpy()]),
+               kl_drho=np.concatenate([lay.W_rho.grad.numpy().ravel(), lay.bias_rho.grad.numpy()]))
+    # Radon (radon/radon.py:23-55) fwd + adjoint
+    for (H, tag) in [(64, "64"), (256, "256")]:
+        img = O.phantom(H, H, 11)
+        theta = torch.arange(0, 180., step=4.)
+        fr = R["radon"].FastRadonTransform((1, 1, H, H), theta)
+        it = torch.from_numpy(img)[None, None].requires_grad_(True)
+        s = fr(it)
+        r = torch.from_numpy(O.normal_fill(11, 2, 5, 0, 0, s.numel()).reshape(s.shape))
+        (s * r).sum().backward()
+        if H == 64:
+            res.update(radon64_sino=s.detach().numpy()[0, 0], radon64_adj=it.grad.numpy()[0, 0])
+        else:
+            res.update(radon256_sino_s=strided(s.detach().numpy()), radon256_adj_s=strided(it.grad.numpy()),
+                       radon256_sino_sum=float(s.sum()), radon256_adj_sum=float(it.grad.sum()))
+    # AdamW(lr, wd=0) 3 steps on a small vector
+    p = torch.from_numpy(O.normal_fill(12, 2, 0, 0, 0, 64).copy()).requires_grad_(True)
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0)
+    for t_ in range(3):
+        opt.zero_grad(); p.grad = torch.from_numpy(O.normal_fill(12, 2, 1 + t_, 0, 0, 64).copy()); opt.step()
+    res.update(adam_p=p.detach().numpy())
+    np.savez_compressed(os.path.join(GOLD, "micro.npz"), **res)
+    print("micro ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    golden_layers()
+    golden_micro()
+    small = O.make_net(32, 32, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+    golden_net("small_den_k2", small, seed=21, K=2, task="den", full_arrays=True)
+    golden_net("small_sr_k1", O.make_net(32, 32, input_depth=8, n_out=2, nd=(8, 16), nu=(8, 16), ns=(4, 4)), seed=22, K=1, task="sr")
+    golden_net("small_ct_k1", O.make_net(32, 32, input_depth=8, n_out=1, nd=(8, 16), nu=(8, 16), ns=(4, 4)), seed=23, K=1, task="ct")
+    golden_net("full_den_64_k1", O.make_net(64, 64), seed=1, K=1, task="den", full_arrays=False)
+    golden_net("full_den_128_k1", O.make_net(128, 128), seed=1, K=1, task="den", full_arrays=False)
+    golden_traj("traj_small_k1", small, seed=31, K=1, steps=4)
+    golden_traj("traj_small_k2", small, seed=32, K=2, steps=3)

@@ -1,0 +1,297 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/mfvi_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmfvi_oracle.so")
+
+MAXS = 8
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mfvi_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libmfvi_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class OracleNet(C.Structure):
+    _fields_ = [("n_scales", C.c_int), ("nd", C.c_int * MAXS), ("nu", C.c_int * MAXS), ("ns", C.c_int * MAXS),
+                ("input_depth", C.c_int), ("n_out", C.c_int), ("fd", C.c_int), ("fu", C.c_int), ("fs", C.c_int),
+                ("H", C.c_int), ("W", C.c_int)]
+
+
+def make_net(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(16, 32, 64, 128, 128), ns=(4, 4, 4, 4, 4),
+             fd=3, fu=3, fs=1):
+    n = OracleNet()
+    n.n_scales = len(nd)
+    for i in range(len(nd)):
+        n.nd[i], n.nu[i], n.ns[i] = nd[i], nu[i], ns[i]
+    n.input_depth, n.n_out, n.fd, n.fu, n.fs, n.H, n.W = input_depth, n_out, fd, fu, fs, H, W
+    return n
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    L.oracle_net_forward.restype = C.c_void_p
+    L.oracle_tape_conv_out.restype = C.c_long
+    L.oracle_tape_cat.restype = C.c_long
+    for name in ("oracle_kl", "oracle_gaussian_nll", "oracle_mse", "oracle_psnr", "oracle_ssim", "oracle_elbo_grad"):
+        getattr(L, name).restype = C.c_double
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---- RNG spec ------------------------------------------------------------------------
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32); k = np.asarray(key, dtype=np.uint32); o = np.zeros(4, np.uint32)
+    lib().oracle_philox(_p(c), _p(k), _p(o))
+    return o
+
+
+def normal_fill(seed, domain, stream, sample, step, n):
+    out = np.zeros(n, np.float32)
+    lib().oracle_normal_fill(C.c_uint64(seed), C.c_uint32(domain), C.c_uint32(stream), C.c_uint32(sample),
+                             C.c_uint32(step), C.c_long(n), _p(out))
+    return out
+
+
+def uniform_fill(seed, stream, sample, step, n):
+    out = np.zeros(n, np.float32)
+    lib().oracle_uniform_fill(C.c_uint64(seed), C.c_uint32(stream), C.c_uint32(sample), C.c_uint32(step), C.c_long(n), _p(out))
+    return out
+
+
+def eps(seed, step, sample, layer, tensor, n):
+    out = np.zeros(n, np.float32)
+    lib().oracle_eps(C.c_uint64(seed), C.c_uint32(step), C.c_uint32(sample), C.c_int(layer), C.c_int(tensor), C.c_long(n), _p(out))
+    return out
+
+
+# ---- elementary ops ------------------------------------------------------------------
+def softplus(x):
+    x = _f(x); o = np.empty_like(x); lib().oracle_softplus(_p(x), C.c_long(x.size), _p(o)); return o
+
+
+def reparam(mu, rho, e):
+    mu, rho, e = _f(mu), _f(rho), _f(e); o = np.empty_like(mu)
+    lib().oracle_reparam(_p(mu), _p(rho), _p(e), C.c_long(mu.size), _p(o)); return o
+
+
+def conv_fwd(x, w, b, stride):
+    x, w = _f(x), _f(w); b = None if b is None else _f(b)
+    cin, H, W = x.shape; cout, _, k, _ = w.shape; p = k // 2
+    Ho, Wo = (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
+    y = np.empty((cout, Ho, Wo), np.float32)
+    lib().oracle_conv_fwd(_p(x), cin, H, W, _p(w), _p(b), cout, k, stride, _p(y))
+    return y
+
+
+def conv_bwd(x, w, stride, dy, need_dx=True):
+    x, w, dy = _f(x), _f(w), _f(dy)
+    cin, H, W = x.shape; cout, _, k, _ = w.shape
+    dx = np.empty_like(x) if need_dx else None
+    dw = np.zeros(w.shape, np.float64); db = np.zeros(cout, np.float64)
+    lib().oracle_conv_bwd(_p(x), cin, H, W, _p(w), cout, k, stride, _p(dy), _p(dx), _p(dw), _p(db))
+    return dx, dw, db
+
+
+def bn_fwd(x, gamma, beta, eps_=1e-5):
+    x, gamma, beta = _f(x), _f(gamma), _f(beta); c = x.shape[0]; hw = x[0].size
+    y = np.empty_like(x); m = np.empty(c, np.float32); r = np.empty(c, np.float32)
+    lib().oracle_bn_fwd(_p(x), c, hw, _p(gamma), _p(beta), C.c_float(eps_), _p(y), _p(m), _p(r))
+    return y, m, r
+
+
+def bn_bwd(x, gamma, mean, rstd, dy):
+    x, gamma, mean, rstd, dy = _f(x), _f(gamma), _f(mean), _f(rstd), _f(dy); c = x.shape[0]; hw = x[0].size
+    dx = np.empty_like(x); dg = np.zeros(c, np.float64); db = np.zeros(c, np.float64)
+    lib().oracle_bn_bwd(_p(x), c, hw, _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dg), _p(db))
+    return dx, dg, db
+
+
+def lrelu_fwd(x, slope=0.2):
+    x = _f(x); y = np.empty_like(x); lib().oracle_lrelu_fwd(_p(x), C.c_long(x.size), C.c_float(slope), _p(y)); return y
+
+
+def upsample2_fwd(x):
+    x = _f(x); c, H, W = x.shape; y = np.empty((c, 2 * H, 2 * W), np.float32)
+    lib().oracle_upsample2_fwd(_p(x), c, H, W, _p(y)); return y
+
+
+def upsample2_bwd(dy):
+    dy = _f(dy); c, Ho, Wo = dy.shape; dx = np.empty((c, Ho // 2, Wo // 2), np.float32)
+    lib().oracle_upsample2_bwd(_p(dy), c, Ho // 2, Wo // 2, _p(dx)); return dx
+
+
+def kl(mu, rho, prior_sigma, prior_mu=0.0, scale=0.0, want_grad=False):
+    mu, rho = _f(mu).ravel(), _f(rho).ravel()
+    dmu = np.zeros_like(mu) if want_grad else None; drho = np.zeros_like(rho) if want_grad else None
+    v = lib().oracle_kl(_p(mu), _p(rho), C.c_long(mu.size), C.c_float(prior_mu), C.c_float(prior_sigma),
+                        C.c_double(scale), _p(dmu), _p(drho))
+    return (v, dmu, drho) if want_grad else v
+
+
+def gaussian_nll(mu, s, target, scale=1.0, want_grad=False):
+    mu, s, target = _f(mu), _f(s), _f(target)
+    dmu = np.empty_like(mu) if want_grad else None; ds = np.empty_like(s) if want_grad else None
+    v = lib().oracle_gaussian_nll(_p(mu), _p(s), _p(target), C.c_long(mu.size), C.c_double(scale), _p(dmu), _p(ds))
+    return (v, dmu, ds) if want_grad else v
+
+
+def mse(a, b, scale=1.0, want_grad=False):
+    a, b = _f(a), _f(b); da = np.empty_like(a) if want_grad else None
+    v = lib().oracle_mse(_p(a), _p(b), C.c_long(a.size), C.c_double(scale), _p(da))
+    return (v, da) if want_grad else v
+
+
+def adam(p, g, m, v, lr, t):
+    """In-place on float32 contiguous arrays."""
+    lib().oracle_adam(_p(p), _p(g), _p(m), _p(v), C.c_long(p.size), C.c_float(lr), C.c_int(t))
+
+
+def psnr(a, b):
+    a, b = _f(a), _f(b); return lib().oracle_psnr(_p(a), _p(b), C.c_long(a.size))
+
+
+def ssim(a, b):
+    a, b = _f(a), _f(b); H, W = a.shape[-2:]; return lib().oracle_ssim(_p(a), _p(b), H, W)
+
+
+def radon_fwd(img, theta_deg):
+    img, theta_deg = _f(img), _f(theta_deg); H, W = img.shape[-2:]; T = theta_deg.size
+    s = np.empty((T, W), np.float32); lib().oracle_radon_fwd(_p(img), H, W, _p(theta_deg), T, _p(s)); return s
+
+
+def radon_adj(dsino, theta_deg, H, W):
+    dsino, theta_deg = _f(dsino), _f(theta_deg); T = theta_deg.size
+    d = np.empty((H, W), np.float32); lib().oracle_radon_adj(_p(dsino), H, W, _p(theta_deg), T, _p(d)); return d
+
+
+# ---- whole net -----------------------------------------------------------------------
+def net_table(net):
+    nc = C.c_int(); nb = C.c_int(); nvi = C.c_long(); nbn = C.c_long()
+    conv = np.zeros((64, 6), np.int64); bn = np.zeros((64, 2), np.int64)
+    lib().oracle_net_table(C.byref(net), C.byref(nc), _p(conv), C.byref(nb), _p(bn), C.byref(nvi), C.byref(nbn))
+    return conv[:nc.value].copy(), bn[:nb.value].copy(), nvi.value, nbn.value
+
+
+class Tape:
+    def __init__(self, net, handle):
+        self.net, self.h = net, C.c_void_p(handle)
+
+    def conv_out(self, conv_id):
+        n = lib().oracle_tape_conv_out(self.h, conv_id, None, None, None)
+        conv, _, _, _ = net_table(self.net)
+        cout = int(conv[conv_id][1])
+        y = np.empty(n, np.float32); m = np.zeros(cout, np.float32); r = np.zeros(cout, np.float32)
+        lib().oracle_tape_conv_out(self.h, conv_id, _p(y), _p(m), _p(r))
+        hw = n // cout; side = int(round(hw ** 0.5))
+        return y.reshape(cout, side, hw // side), m, r
+
+    def cat(self, scale):
+        n = lib().oracle_tape_cat(self.h, scale, None)
+        y = np.empty(n, np.float32); lib().oracle_tape_cat(self.h, scale, _p(y)); return y
+
+    def backward(self, dout, n_vi, n_bnp, want_dz=False):
+        dout = _f(dout)
+        dmu = np.zeros(n_vi, np.float64); drho = np.zeros(n_vi, np.float64); dbn = np.zeros(n_bnp, np.float64)
+        dz = np.empty((self.net.input_depth, self.net.H, self.net.W), np.float32) if want_dz else None
+        lib().oracle_net_backward(self.h, _p(dout), _p(dmu), _p(drho), _p(dbn), _p(dz))
+        return dmu, drho, dbn, dz
+
+    def free(self):
+        if self.h:
+            lib().oracle_tape_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def net_forward(net, mu, rho, bn, z, seed, step, sample, sample_weights=True):
+    """One MC forward (MeanFieldVI.forward).  mu/rho/bn/z must stay alive while the tape is used."""
+    mu, rho, bn, z = _f(mu), _f(rho), _f(bn), _f(z)
+    out = np.empty((net.n_out, net.H, net.W), np.float32)
+    h = lib().oracle_net_forward(C.byref(net), _p(mu), _p(rho), _p(bn), _p(z), C.c_uint64(seed), C.c_uint32(step),
+                                 C.c_uint32(sample), C.c_int(1 if sample_weights else 0), _p(out))
+    t = Tape(net, h); t._keep = (mu, rho, bn, z)
+    return out, t
+
+
+def elbo_grad(net, mu, rho, bn, z, target, task=0, factor=4, theta_deg=None, seed=1, step=0, k0=0, K=1, K_total=None,
+              temp=1.0, prior_sigma=0.1, with_kl=True, want_out=False):
+    mu, rho, bn, z, target = _f(mu), _f(rho), _f(bn), _f(z), _f(target)
+    K_total = K if K_total is None else K_total
+    th = None if theta_deg is None else _f(theta_deg)
+    dmu = np.zeros_like(mu); drho = np.zeros_like(rho); dbn = np.zeros_like(bn)
+    outs = np.empty((K, net.n_out, net.H, net.W), np.float32) if want_out else None
+    nll = C.c_double(); klv = C.c_double()
+    loss = lib().oracle_elbo_grad(C.byref(net), _p(mu), _p(rho), _p(bn), _p(z), _p(target), C.c_int(task), C.c_int(factor),
+                                  _p(th), C.c_int(0 if th is None else th.size), C.c_uint64(seed), C.c_uint32(step),
+                                  C.c_int(k0), C.c_int(K), C.c_int(K_total), C.c_float(temp), C.c_float(prior_sigma),
+                                  C.c_int(1 if with_kl else 0), _p(dmu), _p(drho), _p(dbn), _p(outs),
+                                  C.byref(nll), C.byref(klv))
+    return dict(loss=loss, nll=nll.value, kl=klv.value, dmu=dmu, drho=drho, dbn=dbn, out=outs)
+
+
+# ---- deterministic synthetic inputs ----------------------------------
+def init_params(net, seed):
+    """mu ~ N(0, 0.1^2), rho ~ N(-3, 0.1^2) (modules/module.py:26-30,56-62) from RNG domain INIT;
+    BN gamma = 1, beta = 0 (torch defaults)."""
+    conv, bn, n_vi, n_bnp = net_table(net)
+    mu = 0.1 * normal_fill(seed, 2, 0, 0, 0, n_vi)
+    rho = -3.0 + 0.1 * normal_fill(seed, 2, 1, 0, 0, n_vi)
+    bnp = np.zeros(n_bnp, np.float32)
+    for c, off in bn:
+        bnp[off:off + c] = 1.0
+    return mu.astype(np.float32), rho.astype(np.float32), bnp
+
+
+def phantom(H, W, seed):
+    """Synthetic ground-truth image in [0,1]: soft ellipses + hard bars + smooth texture."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    img = np.zeros((H, W), np.float64)
+    for _ in range(6):
+        cx, cy = rng.uniform(-0.6, 0.6, 2); ax, ay = rng.uniform(0.1, 0.5, 2); th = rng.uniform(0, np.pi)
+        amp = rng.uniform(0.2, 0.6)
+        xr = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); yr = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        img += amp / (1.0 + np.exp(np.minimum(((xr / ax) ** 2 + (yr / ay) ** 2 - 1.0) * 8.0, 60.0)))
+    img[int(0.2 * H):int(0.25 * H), int(0.1 * W):int(0.9 * W)] += 0.3
+    img[int(0.1 * H):int(0.9 * H), int(0.7 * W):int(0.74 * W)] += 0.25
+    img += 0.03 * np.sin(9 * xx) * np.cos(7 * yy)
+    img -= img.min(); img /= img.max()
+    return img.astype(np.float32)
+
+
+def noisy(img, p_sigma, seed):
+    rng = np.random.default_rng(seed + 1)
+    return np.clip(img + rng.normal(scale=p_sigma, size=img.shape), 0, 1).astype(np.float32)
