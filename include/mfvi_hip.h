@@ -1,0 +1,136 @@
+/*
+ * mfvi_hip.h — C ABI of libmfvi_hip.so: the MI355X (gfx950) implementation of the
+ * mean-field-VI deep-image-prior hot path of Cardio-AI/mfvi-dip-mia.
+ *
+ * The reference is pure Python/PyTorch, so there is no existing FFI to mirror; these entry points are
+ * what a ctypes/cffi binding of the reference's path binds (see INTEGRATION.md for the stub).  Each
+ * one names the reference code it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - plain C: opaque handles, raw DEVICE pointers, sizes, a hipStream_t passed as void*.
+ *  - every call is asynchronous on `stream` and allocates nothing; the caller owns all buffers.
+ *  - return value: 0 = ok, <0 = argument/shape error, >0 = hipError_t.  mfvi_last_error() returns a
+ *    thread-local message for the last non-zero return.  Nothing throws across the boundary.
+ *  - tensors are fp32, NCHW with N = MC sample index; parameters live in three flat fp32 blocks
+ *    MU[n_vi], RHO[n_vi], BN[n_bn] (per VI layer: W then bias, in module order; per BatchNorm: gamma
+ *    then beta).  Gradients use the same layout.
+ *  - random numbers follow "RNG spec v1" (DESIGN.md): Philox4x32-10 keyed by seed, counter
+ *    (block, domain<<24|stream, sample, step); eps of VI layer l, tensor t (0 = W, 1 = bias),
+ *    element j is lane j&3 of block j>>2 of stream 2l+t in domain 0.
+ */
+#ifndef MFVI_HIP_H
+#define MFVI_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFVI_ABI_VERSION 1
+
+typedef struct mfvi_plan mfvi_plan;
+
+enum { MFVI_OP_CONV = 1, MFVI_OP_CONCAT_UP = 2 };
+enum { MFVI_UP_BILINEAR = 0 };
+enum { MFVI_TASK_DENOISE = 0, MFVI_TASK_SR = 1 };
+
+/* An activation tensor of the layer program, [C][H][W] per MC sample, stored RAW (conv output or
+ * concat result).  Consumers read view(T) = LeakyReLU?(BatchNorm_train?(T)): the BatchNorm2d (training
+ * mode, batch 1: models/common.py:96-97) and LeakyReLU(0.2) (models/common.py:83) that follow T in
+ * models/skip.py:68-119 are folded into the loads of whatever consumes T. */
+typedef struct {
+    int32_t C, H, W;
+    int32_t has_bn;      /* train-mode BN with per-sample statistics over H*W */
+    int32_t has_act;     /* LeakyReLU(slope) after the BN */
+    float   slope;
+    float   eps;
+    int64_t bn_off;      /* offset of gamma[C] (beta[C] follows) inside the BN block */
+} mfvi_tensor_desc;
+
+/* One fused op.
+ * MFVI_OP_CONV       out = conv2d(reflection_pad(view(in0), ksize/2), w, b, stride), w = mu + softplus(rho)*eps
+ *                    = ReflectionPad2d + Conv2dRT: models/common.py:100-135, BayTorch/modules/reparam_layers.py:26-37,
+ *                      BayTorch/modules/module.py:82-85.
+ * MFVI_OP_CONCAT_UP  out = cat(view(in0), upsample2x_bilinear(view(in1)))  (in0 = -1: upsample only)
+ *                    = Concat + nn.Upsample: models/common.py:23-43, models/skip.py:102. */
+typedef struct {
+    int32_t type;
+    int32_t in0, in1, out;
+    int32_t ksize, stride;
+    int32_t layer_id;        /* VI layer index = RNG stream / 2 */
+    int32_t up_mode;
+    int64_t w_off, b_off;    /* offsets of W and bias inside MU / RHO; b_off < 0: no bias */
+} mfvi_op_desc;
+
+/* ---- layer program (replaces MeanFieldVI.forward / autograd of it: BayTorch/freq_to_bayes.py:40-41) ---- */
+int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_op_desc* ops, int n_ops,
+                     int input_tensor, int output_tensor, int64_t n_vi, int64_t n_bn, int max_samples,
+                     mfvi_plan** plan);
+void mfvi_plan_destroy(mfvi_plan* plan);
+/* bytes of caller-provided device workspace (activations, gradients, BN statistics) for max_samples */
+int64_t mfvi_plan_workspace_bytes(const mfvi_plan* plan);
+
+/* n_samples MC forwards of the net on the SAME input z[Cin][H][W]; sample i uses eps of global sample
+ * index k0+i.  sample_weights = 0 reproduces RTLayer's eval branch (w = mu).  out: [n_samples][Cout][H][W]. */
+int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z,
+                 uint64_t seed, uint32_t step, uint32_t k0, int n_samples, int sample_weights,
+                 void* workspace, float* out, void* stream);
+/* Backward of the same call (workspace must still hold its activations).  dout: [n_samples][Cout][H][W].
+ * dmu/drho/dbn are ACCUMULATED into (+=).  dz (optional): [n_samples][Cin][H][W]. */
+int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z,
+                  uint64_t seed, uint32_t step, uint32_t k0, int n_samples, int sample_weights,
+                  void* workspace, const float* dout, float* dmu, float* drho, float* dbn, float* dz, void* stream);
+/* Debug/parity access: copy tensor `tensor_id` of sample `sample` from the workspace to dst (device):
+ * which = 0: raw activation [C][H][W]; 1: gradient wrt its BN output (valid after mfvi_backward);
+ * 2: its forward BN sums as doubles [C][2] (dst must hold 2*C doubles). */
+int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tensor_id, int sample, int which, void* dst, void* stream);
+
+/* ---- losses -------------------------------------------------------------------------------------------- */
+/* gaussian_nll (utils/bayesian_utils.py:29-32) for n samples of out[n][2][H][W] against target[H/f][W/f];
+ * f > 1 applies the SR projection out[..., ::f, ::f] first (bayesian_optimization.py:2095-2099,2182-2185).
+ * nll_sum (device double) += sum_i nll_i.  dout (optional) = grad_scale * d nll_i / d out_i. */
+int mfvi_gaussian_nll(const float* out, const float* target, int n, int H, int W, int factor,
+                      float grad_scale, float* dout, double* nll_sum, void* stream);
+/* mse_loss(radon(out), sino) (bayesian_optimization.py:576, radon/radon.py:49-53): out[n][1][H][W],
+ * theta_deg[T], sino[T][W]; scratch: n*T*W floats.  mse_sum += sum_i mse_i; dout = grad_scale * d mse_i/d out_i. */
+int mfvi_radon_mse(const float* out, const float* sino, const float* theta_deg, int n, int H, int W, int T,
+                   float grad_scale, float* scratch, float* dout, double* mse_sum, void* stream);
+int mfvi_radon_forward(const float* img, const float* theta_deg, int n, int H, int W, int T, float* sino, void* stream);
+int mfvi_radon_adjoint(const float* dsino, const float* theta_deg, int n, int H, int W, int T, float* dimg, void* stream);
+
+/* ---- KL (VIModule._kl / MeanFieldVI.kl: BayTorch/modules/module.py:64-80, freq_to_bayes.py:43-48) ------- */
+/* kl_out (device double, overwritten) = sum_j log(s_j/s0) + (s0^2 + (mu_j-m0)^2)/(2 s_j^2) - 1/2 */
+int mfvi_kl(const float* mu, const float* rho, int64_t n, float prior_mu, float prior_sigma, double* kl_out, void* stream);
+/* dmu += scale * dKL/dmu, drho += scale * dKL/drho */
+int mfvi_kl_backward(const float* mu, const float* rho, int64_t n, float prior_mu, float prior_sigma, float scale,
+                     float* dmu, float* drho, void* stream);
+
+/* ---- optimizer (torch.optim.AdamW(lr, weight_decay=0): bayesian_optimization.py:1356-1357,1372) --------- */
+int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int t, void* stream);
+
+/* ---- RNG spec v1 on the device ----------------------------------------------------------------------------- */
+/* out[j] = a + b * N(0,1)  (e.g. z = z0 + 0.1*noise uses mfvi_axpy_normal) */
+int mfvi_normal_fill(uint64_t seed, uint32_t domain, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n,
+                     float a, float b, float* out, void* stream);
+int mfvi_uniform_fill(uint64_t seed, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n, float scale,
+                      float* out, void* stream);
+/* net_input = net_input_saved + std * N(0,1)  (bayesian_optimization.py:1363-1364), RNG domain 1 */
+int mfvi_perturb_input(const float* z0, uint64_t seed, uint32_t step, int64_t n, float std, float* z, void* stream);
+
+/* ---- per-iteration bookkeeping (bayesian_optimization.py:1374-1406; utils/common_utils.py:297-353) --------- */
+/* acc[0] += mse(a,b) numerator pieces: returns sum (a-b)^2 over n elements into sum_out (device double, overwritten) */
+int mfvi_sq_err_sum(const float* a, const float* b, int64_t n, double* sum_out, void* stream);
+/* SSIM map mean (11x11 Gaussian sigma 1.5, zero padding) of two [H][W] images; ssim_sum overwritten with the
+ * sum of the SSIM map (divide by H*W). */
+int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum, void* stream);
+/* post-step output handling: mean[n][HW] kept, out[:,1] <- exp(-out[:,1]); ema = ema*w + out*(1-w) (first: copy) */
+int mfvi_post_step(float* out, int n, int C, int H, int W, float* ema, float ema_weight, int first, void* stream);
+
+const char* mfvi_last_error(void);
+int mfvi_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,6 @@
+"""Public surface."""
+from . import _lib
+from ._build import build
+from .program import Plan, Program, skip_program
+
+__all__ = ["build", "Plan", "Program", "skip_program", "_lib"]

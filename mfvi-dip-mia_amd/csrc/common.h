@@ -1,0 +1,245 @@
+// Shared device/host definitions of libmfvi_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MFVI_MAX_C 256           // max channels of any activation tensor handled by the kernels
+
+// ------------------------------------------------------------------------------------------------
+// RNG spec v1.  Written with explicit fmaf / separate mul so that the bits match the
+// CPU oracle's independent restatement (built with -ffp-contract=off).
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1, uint32_t r[4])
+{
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+#else
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+#endif
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+__device__ __forceinline__ float spec_logf(float u)
+{
+    const uint32_t b = __float_as_uint(u);
+    int e = (int)((b >> 23) & 0xffu) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float y = 7.0376836292E-2f;
+    y = __builtin_fmaf(y, f, -1.1514610310E-1f);
+    y = __builtin_fmaf(y, f, 1.1676998740E-1f);
+    y = __builtin_fmaf(y, f, -1.2420140846E-1f);
+    y = __builtin_fmaf(y, f, 1.4249322787E-1f);
+    y = __builtin_fmaf(y, f, -1.6668057665E-1f);
+    y = __builtin_fmaf(y, f, 2.0000714765E-1f);
+    y = __builtin_fmaf(y, f, -2.4999993993E-1f);
+    y = __builtin_fmaf(y, f, 3.3333331174E-1f);
+    y = y * f;
+    y = y * z;
+    const float fe = (float)e;
+    y = __builtin_fmaf(-2.12194440e-4f, fe, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = __builtin_fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+__device__ __forceinline__ void spec_boxmuller(uint32_t a, uint32_t b, float& z0, float& z1)
+{
+    const float u1 = ((float)(a >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float rad = __fsqrt_rn(-2.0f * spec_logf(u1));
+    const uint32_t t = b >> 8;
+    const uint32_t n = (t + 0x200000u) >> 22;
+    const int32_t d = (int32_t)t - (int32_t)(n << 22);
+    const float p = ((float)d * 1.1920928955078125e-07f) * 3.14159265358979323846f;
+    const float z = p * p;
+    float s = -1.9515295891E-4f;
+    s = __builtin_fmaf(s, z, 8.3321608736E-3f);
+    s = __builtin_fmaf(s, z, -1.6666654611E-1f);
+    s = s * z;
+    s = __builtin_fmaf(s, p, p);
+    float c = 2.443315711809948E-005f;
+    c = __builtin_fmaf(c, z, -1.388731625493765E-003f);
+    c = __builtin_fmaf(c, z, 4.166664568298827E-002f);
+    c = c * z;
+    c = c * z;
+    c = __builtin_fmaf(-0.5f, z, c);
+    c = c + 1.0f;
+    const uint32_t q = n & 3u;
+    const float cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    const float sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    z0 = rad * cs;
+    z1 = rad * sn;
+}
+
+enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3 };
+
+struct RngKey {              // everything but the block index
+    uint32_t k0, k1;         // seed lo/hi
+    uint32_t stream;         // (domain << 24) | stream id
+    uint32_t sample, step;
+};
+
+// 4 standard normals of Philox block `blk` (elements 4*blk .. 4*blk+3 of the stream)
+__device__ __forceinline__ void spec_normal4(const RngKey& key, uint32_t blk, float z[4])
+{
+    uint32_t r[4];
+    philox4x32_10(blk, key.stream, key.sample, key.step, key.k0, key.k1, r);
+    spec_boxmuller(r[0], r[1], z[0], z[1]);
+    spec_boxmuller(r[2], r[3], z[2], z[3]);
+}
+
+#pragma clang fp contract(fast)
+
+// torch.nn.functional.softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// Tensor views
+// ------------------------------------------------------------------------------------------------
+// Read side of an activation tensor: raw data + the deferred BatchNorm(train, N=1)/LeakyReLU.
+struct TView {
+    const float* data;       // sample 0
+    long long sstride;       // floats between samples (0: shared by all samples)
+    int C, H, W;
+    const double* stats;     // [n_samples][C][2] = sum, sum of squares; nullptr: no BN
+    const float* gamma;      // gamma[C], beta[C] follows at gamma + C
+    float eps, slope;
+    int act;
+};
+
+// Gradient wrt a raw tensor y, formed on load from ga = dL/d(BN output) (or dL/dy when no BN):
+//   dy = gamma*rstd * (ga - mean(ga) - xhat * mean(ga*xhat))
+struct GView {
+    const float* ga; long long gstride;
+    const float* y;  long long ystride;
+    int C, H, W;
+    const double* stats;     // forward sums of y (nullptr: no BN, dy = ga)
+    const double* bsums;     // [n_samples][C][2] = sum ga, sum ga*xhat
+    const float* gamma;
+    float eps;
+};
+
+// per-channel constants of a view, computed once per block into LDS/registers
+struct ChanFwd { float mean, scale, beta, rstd; };     // v = (y - mean) * scale + beta
+struct ChanBwd { float mean, rstd, c1, c2, c3; };      // dy = c1 * (ga - c2 - xhat*c3), xhat = (y-mean)*rstd
+
+__device__ __forceinline__ ChanFwd chan_fwd(const TView& v, int k, int c)
+{
+    ChanFwd r;
+    if (v.stats == nullptr) { r.mean = 0.f; r.scale = 1.f; r.beta = 0.f; r.rstd = 1.f; return r; }
+    const double n = (double)v.H * (double)v.W;
+    const double* s = v.stats + ((long long)k * v.C + c) * 2;
+    const double m = s[0] / n;
+    double var = s[1] / n - m * m; if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)v.eps);
+    r.mean = (float)m; r.scale = (float)(rstd * (double)v.gamma[c]); r.beta = v.gamma[v.C + c]; r.rstd = (float)rstd;
+    return r;
+}
+__device__ __forceinline__ float apply_fwd(const ChanFwd& c, float y, int act, float slope)
+{
+    float v = __builtin_fmaf(y - c.mean, c.scale, c.beta);
+    if (act) v = v > 0.f ? v : v * slope;
+    return v;
+}
+__device__ __forceinline__ ChanBwd chan_bwd(const GView& g, int k, int c)
+{
+    ChanBwd r;
+    if (g.stats == nullptr) { r.mean = 0.f; r.rstd = 0.f; r.c1 = 1.f; r.c2 = 0.f; r.c3 = 0.f; return r; }
+    const double n = (double)g.H * (double)g.W;
+    const double* s = g.stats + ((long long)k * g.C + c) * 2;
+    const double* b = g.bsums + ((long long)k * g.C + c) * 2;
+    const double m = s[0] / n;
+    double var = s[1] / n - m * m; if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)g.eps);
+    r.mean = (float)m; r.rstd = (float)rstd; r.c1 = (float)(rstd * (double)g.gamma[c]);
+    r.c2 = (float)(b[0] / n); r.c3 = (float)(b[1] / n);
+    return r;
+}
+__device__ __forceinline__ float apply_bwd(const ChanBwd& c, float ga, float y)
+{
+    const float xhat = (y - c.mean) * c.rstd;
+    return c.c1 * (ga - c.c2 - xhat * c.c3);
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block reductions (256-thread blocks, wave = 64)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the block; result valid in thread 0.  `red` is LDS scratch of >= (blockDim.x/64) doubles.
+__device__ __forceinline__ double block_sum_d(double v, double* red)
+{
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-side launch plumbing shared by the .hip files
+// ------------------------------------------------------------------------------------------------
+struct ConvGeom {
+    int Cin, Cout, H, W, Ho, Wo, ks, stride;
+    long long w_off, b_off;    // into mu / rho
+    int layer_id;
+};
+
+struct OutDesc {               // raw output tensor of a forward op
+    float* data; long long sstride;
+    double* stats;             // [n_samples][C][2] to accumulate, or nullptr
+};
+
+void set_error(const char* fmt, ...);
+
+int launch_conv_fwd(const TView& in, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
+                    OutDesc out, int n_samples, hipStream_t st);
+int launch_conv_bwd_data(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
+                         float* dxp, long long dxp_sstride, int n_samples, hipStream_t st);
+int launch_conv_bwd_weight(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
+                           float* dmu, float* drho, int n_samples, hipStream_t st);
+struct FoldSrc { const float* d; long long sstride; int pad; };
+// ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.
+int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,
+                       int n_samples, hipStream_t st);
+int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int n_samples, hipStream_t st);
+int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long ga_a_sstride, double* bsums_a,
+                         const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int n_samples, hipStream_t st);
+struct BnGradEntry { long long bsums_off; long long bn_off; int C; int pad; };
+int launch_bn_param_grads(const BnGradEntry* table_dev, int n_entries, int max_c, const double* bsums_base, int n_samples,
+                          float* dbn, hipStream_t st);

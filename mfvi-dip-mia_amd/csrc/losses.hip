@@ -1,0 +1,267 @@
+// K5/K6/K9/K10 — HBM-bound reductions and element-wise passes of one ELBO iteration:
+// Gaussian NLL (utils/bayesian_utils.py:29-32), KL(prior || posterior) (BayTorch/modules/module.py:64-80),
+// AdamW(wd=0) (bayesian_optimization.py:1356-1357), RNG fills, per-iteration bookkeeping
+// (bayesian_optimization.py:1374-1406, utils/common_utils.py:297-353).
+#include "common.h"
+#include "../../include/mfvi_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* red)
+{
+    const double s = block_sum_d(v, red);
+    if (threadIdx.x == 0) atomicAdd(dst, s);
+}
+
+// ---- gaussian_nll ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_nll_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                           int H, int W, int f, float grad_scale, float* __restrict__ dout,
+                                                           double* __restrict__ nll_sum)
+{
+    __shared__ double s_red[8];
+    const int k = blockIdx.y;
+    const int h = H / f, w = W / f;
+    const long long n = (long long)h * w, HW = (long long)H * W;
+    const float* __restrict__ o = out + (long long)k * 2 * HW;
+    float* __restrict__ d = dout ? dout + (long long)k * 2 * HW : nullptr;
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        const long long p = (long long)(y * f) * W + (long long)x * f;
+        const float m = o[p], sraw = o[HW + p];
+        const float s = fminf(fmaxf(sraw, -20.f), 20.f);
+        const bool inside = (sraw >= -20.f) && (sraw <= 20.f);
+        const float df = target[i] - m, e = expf(s);
+        acc += (double)(e * df * df - s);
+        if (d) {
+            d[p] = grad_scale * (-2.f * e * df) / (float)n;
+            d[HW + p] = inside ? grad_scale * (e * df * df - 1.f) / (float)n : 0.f;
+        }
+    }
+    block_atomic_add(acc / (double)n, nll_sum, s_red);
+}
+
+// ---- KL ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ mu, const float* __restrict__ rho, long long n,
+                                                 float m0, float s0, double* __restrict__ kl_out)
+{
+    __shared__ double s_red[8];
+    double acc = 0;
+    const float log_s0 = logf(s0), s0sq = s0 * s0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float s = softplus_f(rho[i]), d = mu[i] - m0;
+        acc += (double)(logf(s) - log_s0) + (double)((s0sq + d * d) / (2.f * s * s)) - 0.5;
+    }
+    block_atomic_add(acc, kl_out, s_red);
+}
+
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ rho, long long n,
+                                                     float m0, float s0, float scale, float* __restrict__ dmu,
+                                                     float* __restrict__ drho)
+{
+    const float s0sq = s0 * s0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float r = rho[i], s = softplus_f(r), d = mu[i] - m0, inv = 1.f / s;
+        dmu[i] += scale * d * inv * inv;
+        drho[i] += scale * (inv - (s0sq + d * d) * inv * inv * inv) * sigmoid_f(r);
+    }
+}
+
+// ---- AdamW(wd = 0) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float b1, float b2, float eps,
+                                                   float step_size, float inv_sqrt_bc2)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+
+// ---- RNG fills ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normal_fill_kernel(RngKey key, long long n, float a, float b, const float* __restrict__ base,
+                                                          float* __restrict__ out)
+{
+    const long long nblk = (n + 3) >> 2;
+    for (long long blk = (long long)blockIdx.x * 256 + threadIdx.x; blk < nblk; blk += (long long)gridDim.x * 256) {
+        float z[4]; spec_normal4(key, (uint32_t)blk, z);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const long long j = blk * 4 + l;
+            if (j < n) out[j] = (base ? base[j] : a) + b * z[l];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void uniform_fill_kernel(RngKey key, long long n, float scale, float* __restrict__ out)
+{
+    const long long nblk = (n + 3) >> 2;
+    for (long long blk = (long long)blockIdx.x * 256 + threadIdx.x; blk < nblk; blk += (long long)gridDim.x * 256) {
+        uint32_t r[4]; philox4x32_10((uint32_t)blk, key.stream, key.sample, key.step, key.k0, key.k1, r);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const long long j = blk * 4 + l;
+            if (j < n) out[j] = scale * ((float)(r[l] >> 8) * 5.9604644775390625e-08f);
+        }
+    }
+}
+
+// ---- bookkeeping -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sq_err_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                     double* __restrict__ out)
+{
+    __shared__ double s_red[8];
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = a[i] - b[i]; acc += (double)(d * d);
+    }
+    block_atomic_add(acc, out, s_red);
+}
+
+struct SsimWin { float g[11]; };
+
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, int H, int W,
+                                                   SsimWin win, double* __restrict__ out)
+{
+    __shared__ double s_red[8];
+    const long long n = (long long)H * W;
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        float m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
+        for (int dy = 0; dy < 11; ++dy) {
+            const int yy = y + dy - 5; if (yy < 0 || yy >= H) continue;
+            for (int dx = 0; dx < 11; ++dx) {
+                const int xx = x + dx - 5; if (xx < 0 || xx >= W) continue;
+                const float wv = win.g[dy] * win.g[dx], p = a[(long long)yy * W + xx], q = b[(long long)yy * W + xx];
+                m1 += wv * p; m2 += wv * q; s11 += wv * p * p; s22 += wv * q * q; s12 += wv * p * q;
+            }
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float v1 = s11 - m1 * m1, v2 = s22 - m2 * m2, v12 = s12 - m1 * m2;
+        acc += (double)(((2.f * m1 * m2 + C1) * (2.f * v12 + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2)));
+    }
+    block_atomic_add(acc, out, s_red);
+}
+
+__global__ __launch_bounds__(256) void post_step_kernel(float* __restrict__ out, int n, int C, long long HW, float* __restrict__ ema,
+                                                        float w, int first)
+{
+    // out[:, 1:] = exp(-out[:, 1:]) (bayesian_optimization.py:1374-1375); EMA over sample 0 (:1378-1381)
+    const long long per = (long long)C * HW, total = (long long)n * per;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i % per; const int c = (int)(r / HW);
+        float v = out[i];
+        if (c >= 1) { v = expf(-v); out[i] = v; }
+        if (ema && i < per) ema[i] = first ? v : ema[i] * w + v * (1.f - w);
+    }
+}
+
+inline int nblocks(long long n, int cap = 2048) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+inline RngKey make_key(uint64_t seed, uint32_t domain, uint32_t stream, uint32_t sample, uint32_t step)
+{
+    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = (domain << 24) | stream; k.sample = sample; k.step = step;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfvi_gaussian_nll(const float* out, const float* target, int n, int H, int W, int factor, float grad_scale, float* dout,
+                      double* nll_sum, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 1 || factor < 1 || H % factor || W % factor) { set_error("gaussian_nll: bad shape n=%d H=%d W=%d factor=%d", n, H, W, factor); return -1; }
+    if (dout && factor > 1) { hipError_t e = hipMemsetAsync(dout, 0, sizeof(float) * (size_t)n * 2 * H * W, st); if (e) return (int)e; }
+    const long long npix = (long long)(H / factor) * (W / factor);
+    hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nblocks(npix, 256), n), dim3(256), 0, st, out, target, H, W, factor, grad_scale, dout, nll_sum);
+    return (int)hipGetLastError();
+}
+
+int mfvi_kl(const float* mu, const float* rho, int64_t n, float prior_mu, float prior_sigma, double* kl_out, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 0 || !(prior_sigma > 0.f)) { set_error("kl: bad arguments"); return -1; }
+    hipError_t e = hipMemsetAsync(kl_out, 0, sizeof(double), st); if (e) return (int)e;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(kl_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, st, mu, rho, (long long)n, prior_mu, prior_sigma, kl_out);
+    return (int)hipGetLastError();
+}
+
+int mfvi_kl_backward(const float* mu, const float* rho, int64_t n, float prior_mu, float prior_sigma, float scale, float* dmu,
+                     float* drho, void* stream)
+{
+    if (n < 0 || !(prior_sigma > 0.f)) { set_error("kl_backward: bad arguments"); return -1; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, mu, rho, (long long)n, prior_mu, prior_sigma, scale, dmu, drho);
+    return (int)hipGetLastError();
+}
+
+int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
+                   void* stream)
+{
+    if (n < 0 || t < 1) { set_error("adam_step: bad arguments (t is 1-based)"); return -1; }
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+    return (int)hipGetLastError();
+}
+
+int mfvi_normal_fill(uint64_t seed, uint32_t domain, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n, float a, float b,
+                     float* out, void* stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       make_key(seed, domain, stream_id, sample, step), (long long)n, a, b, (const float*)nullptr, out);
+    return (int)hipGetLastError();
+}
+
+int mfvi_uniform_fill(uint64_t seed, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n, float scale, float* out, void* stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(uniform_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       make_key(seed, DOMAIN_UNIFORM, stream_id, sample, step), (long long)n, scale, out);
+    return (int)hipGetLastError();
+}
+
+int mfvi_perturb_input(const float* z0, uint64_t seed, uint32_t step, int64_t n, float std, float* z, void* stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       make_key(seed, DOMAIN_INPUT, 0, 0, step), (long long)n, 0.f, std, z0, z);
+    return (int)hipGetLastError();
+}
+
+int mfvi_sq_err_sum(const float* a, const float* b, int64_t n, double* sum_out, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sum_out, 0, sizeof(double), st); if (e) return (int)e;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sq_err_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, a, b, (long long)n, sum_out);
+    return (int)hipGetLastError();
+}
+
+int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ssim_sum, 0, sizeof(double), st); if (e) return (int)e;
+    SsimWin win; float s = 0.f;
+    for (int i = 0; i < 11; ++i) { win.g[i] = expf(-(float)((i - 5) * (i - 5)) / (2.f * 1.5f * 1.5f)); s += win.g[i]; }
+    for (int i = 0; i < 11; ++i) win.g[i] /= s;
+    hipLaunchKernelGGL(ssim_kernel, dim3(nblocks((long long)H * W, 1024)), dim3(256), 0, st, a, b, H, W, win, ssim_sum);
+    return (int)hipGetLastError();
+}
+
+int mfvi_post_step(float* out, int n, int C, int H, int W, float* ema, float ema_weight, int first, void* stream)
+{
+    const long long total = (long long)n * C * H * W;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(post_step_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, out, n, C, (long long)H * W, ema, ema_weight, first);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

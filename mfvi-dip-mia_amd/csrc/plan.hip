@@ -1,0 +1,347 @@
+// Host side of libmfvi_hip: the layer-program planner/executor behind mfvi_plan_* / mfvi_forward /
+// mfvi_backward (include/mfvi_hip.h).  It validates the fused-op program emitted by the Python front-end
+// (which walks the reference's module tree: models/skip.py:58-134), lays the activations, gradients and
+// BN statistics out in one caller-provided workspace, and issues the kernels on the caller's stream.
+#include "common.h"
+#include "../../include/mfvi_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+
+namespace {
+
+struct TensorInfo {
+    mfvi_tensor_desc d;
+    long long numel = 0;
+    long long act_off = -1, ga_off = -1;       // floats, from the float arena base
+    long long stats_off = -1;                  // doubles, inside the fwd-stats block (same offset in the bsums block)
+    int producer = -1;
+    std::vector<int> consumers;                // op indices, forward order
+};
+
+struct OpInfo {
+    mfvi_op_desc d;
+    ConvGeom g;
+    long long scratch_off = -1;                // floats: padded input-gradient scratch of this conv
+};
+
+inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct mfvi_plan {
+    std::vector<TensorInfo> t;
+    std::vector<OpInfo> ops;
+    int input = -1, output = -1, max_samples = 0;
+    long long n_vi = 0, n_bn = 0;
+    long long stats_doubles = 0;               // per block (fwd stats | bsums), for max_samples
+    long long float_base = 0;                  // byte offset of the float arena
+    long long total_bytes = 0;
+    BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
+};
+
+namespace {
+
+bool fail(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return false;
+}
+
+bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc* od, int n_ops)
+{
+    if (n_t < 2 || n_ops < 1) return fail("plan: need >= 2 tensors and >= 1 op");
+    if (p.input < 0 || p.input >= n_t || p.output < 0 || p.output >= n_t || p.input == p.output)
+        return fail("plan: bad input/output tensor ids %d/%d", p.input, p.output);
+    if (p.max_samples < 1) return fail("plan: max_samples must be >= 1");
+    p.t.resize(n_t); p.ops.resize(n_ops);
+    for (int i = 0; i < n_t; ++i) {
+        TensorInfo& ti = p.t[i]; ti.d = td[i];
+        if (ti.d.C < 1 || ti.d.H < 1 || ti.d.W < 1 || ti.d.C > MFVI_MAX_C) return fail("plan: tensor %d has bad shape (%d,%d,%d)", i, ti.d.C, ti.d.H, ti.d.W);
+        if (ti.d.has_act && !ti.d.has_bn) return fail("plan: tensor %d: activation without BatchNorm is not part of the skip() family", i);
+        if (ti.d.has_bn && (ti.d.bn_off < 0 || ti.d.bn_off + 2LL * ti.d.C > p.n_bn)) return fail("plan: tensor %d: bn_off out of range", i);
+        ti.numel = (long long)ti.d.C * ti.d.H * ti.d.W;
+    }
+    if (p.t[p.input].d.has_bn) return fail("plan: the input tensor cannot carry a BatchNorm");
+    if (p.t[p.output].d.has_bn) return fail("plan: the output tensor must be raw (no BatchNorm/activation)");
+    for (int i = 0; i < n_ops; ++i) {
+        OpInfo& o = p.ops[i]; o.d = od[i];
+        const mfvi_op_desc& d = o.d;
+        if (d.out < 0 || d.out >= n_t || d.out == p.input) return fail("plan: op %d: bad output tensor", i);
+        if (p.t[d.out].producer >= 0) return fail("plan: tensor %d produced twice", d.out);
+        p.t[d.out].producer = i;
+        if (d.type == MFVI_OP_CONV) {
+            if (d.in0 < 0 || d.in0 >= n_t) return fail("plan: op %d: bad input tensor", i);
+            const TensorInfo& x = p.t[d.in0]; const TensorInfo& y = p.t[d.out];
+            if (!((d.ksize == 3 && (d.stride == 1 || d.stride == 2)) || (d.ksize == 1 && d.stride == 1)))
+                return fail("plan: op %d: conv ksize %d stride %d not supported (3x3 s1/s2, 1x1 s1)", i, d.ksize, d.stride);
+            const int P = d.ksize / 2;
+            const int Ho = (x.d.H + 2 * P - d.ksize) / d.stride + 1, Wo = (x.d.W + 2 * P - d.ksize) / d.stride + 1;
+            if (Ho != y.d.H || Wo != y.d.W) return fail("plan: op %d: output spatial size (%d,%d) != expected (%d,%d)", i, y.d.H, y.d.W, Ho, Wo);
+            if (P > 0 && (x.d.H < 2 || x.d.W < 2)) return fail("plan: op %d: reflection padding needs H,W >= 2", i);
+            const long long nw = (long long)y.d.C * x.d.C * d.ksize * d.ksize;
+            if (d.w_off < 0 || d.w_off + nw > p.n_vi) return fail("plan: op %d: w_off out of range", i);
+            if (d.b_off >= 0 && d.b_off + y.d.C > p.n_vi) return fail("plan: op %d: b_off out of range", i);
+            if (d.layer_id < 0 || d.layer_id >= (1 << 22)) return fail("plan: op %d: bad layer_id", i);
+            o.g = ConvGeom{x.d.C, y.d.C, x.d.H, x.d.W, Ho, Wo, d.ksize, d.stride, d.w_off, d.b_off, d.layer_id};
+            p.t[d.in0].consumers.push_back(i);
+        } else if (d.type == MFVI_OP_CONCAT_UP) {
+            if (d.in1 < 0 || d.in1 >= n_t || d.in0 >= n_t) return fail("plan: op %d: bad input tensors", i);
+            if (d.up_mode != MFVI_UP_BILINEAR) return fail("plan: op %d: only bilinear upsampling is implemented", i);
+            const TensorInfo& b = p.t[d.in1]; const TensorInfo& y = p.t[d.out];
+            int Ca = 0;
+            if (d.in0 >= 0) {
+                const TensorInfo& a = p.t[d.in0]; Ca = a.d.C;
+                // Concat centre-crops to the smaller input (models/common.py:31-41); only the no-crop case is built
+                if (a.d.H != 2 * b.d.H || a.d.W != 2 * b.d.W) return fail("plan: op %d: concat inputs differ in size (%dx%d vs 2*%dx%d): centre-crop not implemented; use H,W divisible by 2^n_scales", i, a.d.H, a.d.W, b.d.H, b.d.W);
+                if (d.in0 == p.input) return fail("plan: op %d: the net input cannot feed a concat", i);
+                p.t[d.in0].consumers.push_back(i);
+            }
+            if (d.in1 == p.input) return fail("plan: op %d: the net input cannot feed an upsample", i);
+            if (y.d.C != Ca + b.d.C || y.d.H != 2 * b.d.H || y.d.W != 2 * b.d.W) return fail("plan: op %d: concat output shape mismatch", i);
+            p.t[d.in1].consumers.push_back(i);
+        } else return fail("plan: op %d: unknown type %d", i, d.type);
+        // inputs must already be produced (program order = execution order)
+        const int ins[2] = {d.in0, d.type == MFVI_OP_CONCAT_UP ? d.in1 : -1};
+        for (int q = 0; q < 2; ++q)
+            if (ins[q] >= 0 && ins[q] != p.input && (p.t[ins[q]].producer < 0 || p.t[ins[q]].producer >= i))
+                return fail("plan: op %d reads tensor %d before it is produced", i, ins[q]);
+    }
+    for (int i = 0; i < n_t; ++i) {
+        if (i != p.input && p.t[i].producer < 0) return fail("plan: tensor %d is never produced", i);
+        if (i != p.output && p.t[i].consumers.empty()) return fail("plan: tensor %d is never consumed", i);
+        if (i == p.output && !p.t[i].consumers.empty()) return fail("plan: the output tensor has consumers");
+        bool cat = false;
+        for (int c : p.t[i].consumers) cat |= p.ops[c].d.type == MFVI_OP_CONCAT_UP;
+        if (cat && p.t[i].consumers.size() != 1) return fail("plan: tensor %d feeds a concat and something else", i);
+        if (p.t[i].consumers.size() > 2) return fail("plan: tensor %d has %d consumers (max 2)", i, (int)p.t[i].consumers.size());
+    }
+    // ---- workspace layout ----
+    long long sd = 0;
+    std::vector<BnGradEntry> table;
+    for (int i = 0; i < n_t; ++i)
+        if (p.t[i].d.has_bn) {
+            p.t[i].stats_off = sd; sd += (long long)p.max_samples * p.t[i].d.C * 2;
+            BnGradEntry e; e.bsums_off = p.t[i].stats_off; e.bn_off = p.t[i].d.bn_off; e.C = p.t[i].d.C; e.pad = 0;
+            table.push_back(e); if (p.t[i].d.C > p.max_c) p.max_c = p.t[i].d.C;
+        }
+    p.stats_doubles = align_up(sd, 32);
+    p.float_base = 2 * p.stats_doubles * (long long)sizeof(double);
+    long long fo = 0;
+    auto take = [&](long long n) { const long long o = fo; fo += align_up(n, 64); return o; };
+    for (int i = 0; i < n_t; ++i) {
+        if (i != p.input && i != p.output) p.t[i].act_off = take(p.t[i].numel * p.max_samples);
+        if (i != p.output && i != p.input) p.t[i].ga_off = take(p.t[i].numel * p.max_samples);
+    }
+    long long shared_scratch = 0;
+    for (auto& o : p.ops)
+        if (o.d.type == MFVI_OP_CONV) {
+            const int P = o.g.ks / 2;
+            const long long n = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P) * p.max_samples;
+            if (p.t[o.d.in0].consumers.size() > 1) o.scratch_off = take(n);       // lives until the fold of in0
+            else if (n > shared_scratch) shared_scratch = n;
+        }
+    const long long shared_off = take(shared_scratch);
+    for (auto& o : p.ops) if (o.d.type == MFVI_OP_CONV && o.scratch_off < 0) o.scratch_off = shared_off;
+    p.total_bytes = p.float_base + fo * (long long)sizeof(float);
+    p.n_entries = (int)table.size();
+    if (p.n_entries) {
+        hipError_t e = hipMalloc((void**)&p.table_dev, sizeof(BnGradEntry) * table.size());
+        if (e != hipSuccess) return fail("plan: hipMalloc of the BN table failed: %s", hipGetErrorString(e));
+        e = hipMemcpy(p.table_dev, table.data(), sizeof(BnGradEntry) * table.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail("plan: hipMemcpy of the BN table failed: %s", hipGetErrorString(e));
+    }
+    return true;
+}
+
+struct Ctx {
+    const mfvi_plan& p; char* ws; const float* bn; const float* z; int n;
+    double* fstats() const { return (double*)ws; }
+    double* bsums() const { return (double*)ws + p.stats_doubles; }
+    float* farena() const { return (float*)(ws + p.float_base); }
+    TView view(int i, const float* out_ptr = nullptr) const
+    {
+        const TensorInfo& t = p.t[i]; TView v;
+        if (i == p.input) { v.data = z; v.sstride = 0; }
+        else if (i == p.output) { v.data = out_ptr; v.sstride = t.numel; }
+        else { v.data = farena() + t.act_off; v.sstride = t.numel; }
+        v.C = t.d.C; v.H = t.d.H; v.W = t.d.W;
+        v.stats = t.d.has_bn ? fstats() + t.stats_off : nullptr;
+        v.gamma = t.d.has_bn ? bn + t.d.bn_off : nullptr;
+        v.eps = t.d.eps; v.slope = t.d.slope; v.act = t.d.has_act;
+        return v;
+    }
+    GView gview(int i, const float* dout) const
+    {
+        const TensorInfo& t = p.t[i]; GView g;
+        g.ga = (i == p.output) ? dout : farena() + t.ga_off; g.gstride = t.numel;
+        g.y = (i == p.output) ? nullptr : farena() + t.act_off; g.ystride = t.numel;
+        g.C = t.d.C; g.H = t.d.H; g.W = t.d.W;
+        g.stats = t.d.has_bn ? fstats() + t.stats_off : nullptr;
+        g.bsums = t.d.has_bn ? bsums() + t.stats_off : nullptr;
+        g.gamma = t.d.has_bn ? bn + t.d.bn_off : nullptr;
+        g.eps = t.d.eps;
+        return g;
+    }
+};
+
+bool check_call(const mfvi_plan* p, int n_samples, const void* ws)
+{
+    if (!p) return fail("null plan");
+    if (!ws) return fail("null workspace");
+    if (n_samples < 1 || n_samples > p->max_samples) return fail("n_samples %d outside 1..%d", n_samples, p->max_samples);
+    return true;
+}
+
+RngKey base_key(uint64_t seed, uint32_t step, uint32_t k0)
+{
+    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = 0; k.sample = k0; k.step = step; return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_op_desc* ops, int n_ops, int input_tensor,
+                     int output_tensor, int64_t n_vi, int64_t n_bn, int max_samples, mfvi_plan** plan)
+{
+    if (!tensors || !ops || !plan) { set_error("plan_create: null argument"); return -1; }
+    mfvi_plan* p = new mfvi_plan();
+    p->input = input_tensor; p->output = output_tensor; p->n_vi = n_vi; p->n_bn = n_bn; p->max_samples = max_samples;
+    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); delete p; *plan = nullptr; return -1; }
+    *plan = p;
+    return 0;
+}
+
+void mfvi_plan_destroy(mfvi_plan* plan)
+{
+    if (!plan) return;
+    if (plan->table_dev) (void)hipFree(plan->table_dev);
+    delete plan;
+}
+
+int64_t mfvi_plan_workspace_bytes(const mfvi_plan* plan) { return plan ? plan->total_bytes : -1; }
+
+int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, uint64_t seed, uint32_t step,
+                 uint32_t k0, int n_samples, int sample_weights, void* workspace, float* out, void* stream)
+{
+    if (!check_call(plan, n_samples, workspace)) return -1;
+    if (!mu || !rho || !z || !out || (plan->n_bn > 0 && !bn)) { set_error("forward: null pointer argument"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    Ctx c{*plan, (char*)workspace, bn, z, n_samples};
+    if (plan->stats_doubles) {
+        hipError_t e = hipMemsetAsync(c.fstats(), 0, sizeof(double) * plan->stats_doubles, st);
+        if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    const RngKey key = base_key(seed, step, k0);
+    for (size_t i = 0; i < plan->ops.size(); ++i) {
+        const OpInfo& o = plan->ops[i];
+        const TensorInfo& y = plan->t[o.d.out];
+        OutDesc od;
+        od.data = (o.d.out == plan->output) ? out : c.farena() + y.act_off; od.sstride = y.numel;
+        od.stats = y.d.has_bn ? c.fstats() + y.stats_off : nullptr;
+        int rc;
+        if (o.d.type == MFVI_OP_CONV) {
+            rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
+        } else {
+            TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
+            rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, n_samples, st);
+        }
+        if (rc) { if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    return 0;
+}
+
+int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, uint64_t seed, uint32_t step,
+                  uint32_t k0, int n_samples, int sample_weights, void* workspace, const float* dout, float* dmu, float* drho,
+                  float* dbn, float* dz, void* stream)
+{
+    if (!check_call(plan, n_samples, workspace)) return -1;
+    if (!mu || !rho || !z || !dout || !dmu || !drho || (plan->n_bn > 0 && (!bn || !dbn))) { set_error("backward: null pointer argument"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    Ctx c{*plan, (char*)workspace, bn, z, n_samples};
+    if (plan->stats_doubles) {
+        hipError_t e = hipMemsetAsync(c.bsums(), 0, sizeof(double) * plan->stats_doubles, st);
+        if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    const RngKey key = base_key(seed, step, k0);
+    for (int i = (int)plan->ops.size() - 1; i >= 0; --i) {
+        const OpInfo& o = plan->ops[i];
+        int rc = 0;
+        if (o.d.type == MFVI_OP_CONV) {
+            const GView gy = c.gview(o.d.out, dout);
+            const TView xin = c.view(o.d.in0);
+            rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st);
+            const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
+            if (!rc && need_dx) {
+                const int P = o.g.ks / 2;
+                const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
+                rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st);
+                const TensorInfo& x = plan->t[o.d.in0];
+                if (!rc && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
+                    FoldSrc srcs[2]; int ns = 0;
+                    for (int ci : x.consumers) {
+                        const OpInfo& co = plan->ops[ci]; const int Pc = co.g.ks / 2;
+                        srcs[ns].d = c.farena() + co.scratch_off;
+                        srcs[ns].sstride = (long long)co.g.Cin * (co.g.H + 2 * Pc) * (co.g.W + 2 * Pc);
+                        srcs[ns].pad = Pc; ++ns;
+                    }
+                    float* ga = (o.d.in0 == plan->input) ? dz : c.farena() + x.ga_off;
+                    rc = launch_finalize_dx(srcs, ns, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
+                }
+            }
+        } else {
+            const GView gc = c.gview(o.d.out, dout);
+            const TensorInfo& b = plan->t[o.d.in1];
+            TView a; float* ga_a = nullptr; long long sa = 0; double* bs_a = nullptr;
+            if (o.d.in0 >= 0) {
+                const TensorInfo& ta = plan->t[o.d.in0];
+                a = c.view(o.d.in0); ga_a = c.farena() + ta.ga_off; sa = ta.numel; bs_a = ta.d.has_bn ? c.bsums() + ta.stats_off : nullptr;
+            }
+            rc = launch_concat_up_bwd(gc, o.d.in0 >= 0 ? &a : nullptr, ga_a, sa, bs_a, c.view(o.d.in1), c.farena() + b.ga_off, b.numel,
+                                      b.d.has_bn ? c.bsums() + b.stats_off : nullptr, n_samples, st);
+        }
+        if (rc) { if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    if (plan->n_entries) {
+        const int rc = launch_bn_param_grads(plan->table_dev, plan->n_entries, plan->max_c, c.bsums(), n_samples, dbn, st);
+        if (rc) { set_error("backward: bn_param_grads launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    return 0;
+}
+
+int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tensor_id, int sample, int which, void* dst, void* stream)
+{
+    if (!plan || !workspace || !dst) { set_error("read_tensor: null argument"); return -1; }
+    if (tensor_id < 0 || tensor_id >= (int)plan->t.size() || tensor_id == plan->input || tensor_id == plan->output) {
+        set_error("read_tensor: tensor %d is not a workspace tensor", tensor_id); return -1; }
+    if (sample < 0 || sample >= plan->max_samples) { set_error("read_tensor: bad sample"); return -1; }
+    const TensorInfo& t = plan->t[tensor_id];
+    const char* ws = (const char*)workspace;
+    const void* src; size_t bytes;
+    if (which == 0 || which == 1) {
+        const float* base = (const float*)(ws + plan->float_base) + (which == 0 ? t.act_off : t.ga_off);
+        src = base + (long long)sample * t.numel; bytes = sizeof(float) * t.numel;
+    } else if (which == 2 || which == 3) {
+        if (!t.d.has_bn) { set_error("read_tensor: tensor %d has no BatchNorm", tensor_id); return -1; }
+        const double* base = (const double*)ws + (which == 3 ? plan->stats_doubles : 0) + t.stats_off;
+        src = base + (long long)sample * t.d.C * 2; bytes = sizeof(double) * t.d.C * 2;
+    } else { set_error("read_tensor: bad selector %d", which); return -1; }
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("read_tensor: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+const char* mfvi_last_error(void) { return g_err; }
+int mfvi_abi_version(void) { return MFVI_ABI_VERSION; }
+
+}  // extern "C"

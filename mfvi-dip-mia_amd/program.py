@@ -1,0 +1,141 @@
+"""Layer program = the fused-op description of a skip()-family network that libmfvi_hip executes.
+
+`Program` is built by walking a module tree (bayes.py) or by hand (tests); `Plan` owns the compiled
+plan handle plus its device workspace and exposes forward/backward on torch CUDA tensors.
+"""
+import ctypes as C
+
+from . import _lib as L
+
+
+class Program:
+    def __init__(self):
+        self.tensors = []          # TensorDesc fields as dicts
+        self.ops = []
+        self.n_vi = 0
+        self.n_bn = 0
+        self.layers = []           # per VI layer: dict(cin, cout, k, stride, w_off, b_off)
+        self.bns = []              # per BN: dict(C, off, tensor)
+
+    def tensor(self, C_, H, W, bn=False, act=False, slope=0.2, eps=1e-5):
+        off = -1
+        if bn:
+            off = self.n_bn
+            self.n_bn += 2 * C_
+            self.bns.append(dict(C=C_, off=off, tensor=len(self.tensors)))
+        self.tensors.append(dict(C=C_, H=H, W=W, has_bn=int(bn), has_act=int(act), slope=slope, eps=eps, bn_off=off))
+        return len(self.tensors) - 1
+
+    def set_bn(self, tid, act, slope=0.2, eps=1e-5):
+        """Attach the BatchNorm (and optional LeakyReLU) that FOLLOWS tensor `tid` in the module order."""
+        t = self.tensors[tid]
+        if t["has_bn"]:
+            raise ValueError("tensor %d already has a BatchNorm" % tid)
+        t.update(has_bn=1, has_act=int(act), slope=slope, eps=eps, bn_off=self.n_bn)
+        self.bns.append(dict(C=t["C"], off=self.n_bn, tensor=tid))
+        self.n_bn += 2 * t["C"]
+
+    def conv(self, in_id, out_id, ksize, stride=1, bias=True):
+        cin, cout = self.tensors[in_id]["C"], self.tensors[out_id]["C"]
+        w_off = self.n_vi
+        self.n_vi += cout * cin * ksize * ksize
+        b_off = -1
+        if bias:
+            b_off = self.n_vi
+            self.n_vi += cout
+        lid = len(self.layers)
+        self.layers.append(dict(cin=cin, cout=cout, k=ksize, stride=stride, w_off=w_off, b_off=b_off))
+        self.ops.append(dict(type=L.OP_CONV, in0=in_id, in1=-1, out=out_id, ksize=ksize, stride=stride, layer_id=lid,
+                             up_mode=0, w_off=w_off, b_off=b_off))
+        return lid
+
+    def concat_up(self, in0, in1, out_id):
+        self.ops.append(dict(type=L.OP_CONCAT_UP, in0=-1 if in0 is None else in0, in1=in1, out=out_id, ksize=0, stride=0,
+                             layer_id=0, up_mode=0, w_off=0, b_off=-1))
+
+    def conv_out_hw(self, in_id, ksize, stride):
+        t = self.tensors[in_id]
+        p = ksize // 2
+        return (t["H"] + 2 * p - ksize) // stride + 1, (t["W"] + 2 * p - ksize) // stride + 1
+
+    def compile(self, input_id, output_id, max_samples):
+        return Plan(self, input_id, output_id, max_samples)
+
+
+class Plan:
+    """Compiled program + workspace on the current CUDA device."""
+
+    def __init__(self, prog, input_id, output_id, max_samples):
+        import torch
+        self.prog, self.input_id, self.output_id, self.max_samples = prog, input_id, output_id, max_samples
+        td = (L.TensorDesc * len(prog.tensors))(*[L.TensorDesc(**t) for t in prog.tensors])
+        od = (L.OpDesc * len(prog.ops))(*[L.OpDesc(**o) for o in prog.ops])
+        h = C.c_void_p()
+        L.check(L.lib().mfvi_plan_create(td, len(prog.tensors), od, len(prog.ops), input_id, output_id, prog.n_vi, prog.n_bn,
+                                         max_samples, C.byref(h)))
+        self.handle = h
+        self.workspace_bytes = L.lib().mfvi_plan_workspace_bytes(h)
+        self.workspace = torch.empty(max(self.workspace_bytes, 16), dtype=torch.uint8, device="cuda")
+        self.in_shape = tuple(prog.tensors[input_id][k] for k in ("C", "H", "W"))
+        self.out_shape = tuple(prog.tensors[output_id][k] for k in ("C", "H", "W"))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.lib().mfvi_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, mu, rho, bn, z, seed, step, k0, n_samples, sample_weights=True, out=None):
+        import torch
+        if out is None:
+            out = torch.empty((n_samples,) + self.out_shape, dtype=torch.float32, device="cuda")
+        assert z.is_contiguous() and z.dtype == torch.float32 and z.numel() == self.in_shape[0] * self.in_shape[1] * self.in_shape[2]
+        L.check(L.lib().mfvi_forward(self.handle, L.ptr(mu), L.ptr(rho), L.ptr(bn), L.ptr(z), seed, step, k0, n_samples,
+                                     int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(out), L.stream_ptr()))
+        return out
+
+    def backward(self, mu, rho, bn, z, seed, step, k0, n_samples, dout, dmu, drho, dbn, sample_weights=True, dz=None):
+        assert dout.is_contiguous() and dout.numel() == n_samples * self.out_shape[0] * self.out_shape[1] * self.out_shape[2]
+        L.check(L.lib().mfvi_backward(self.handle, L.ptr(mu), L.ptr(rho), L.ptr(bn), L.ptr(z), seed, step, k0, n_samples,
+                                      int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(dout), L.ptr(dmu), L.ptr(drho),
+                                      L.ptr(dbn), L.ptr(dz), L.stream_ptr()))
+
+    def read_tensor(self, tid, sample=0, which=0):
+        import torch
+        t = self.prog.tensors[tid]
+        if which in (0, 1):
+            dst = torch.empty((t["C"], t["H"], t["W"]), dtype=torch.float32, device="cuda")
+        else:
+            dst = torch.empty((t["C"], 2), dtype=torch.float64, device="cuda")
+        L.check(L.lib().mfvi_plan_read_tensor(self.handle, L.ptr(self.workspace), tid, sample, which, L.ptr(dst), L.stream_ptr()))
+        return dst
+
+
+def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(16, 32, 64, 128, 128), ns=(4, 4, 4, 4, 4),
+                 fd=3, fu=3, fs=1):
+    """The skip() hour-glass of the reference (models/skip.py:58-134) as a layer program, in module order:
+    per scale  skip-conv/BN/act, down-conv(s2)/BN/act, conv/BN/act, [deeper scale], Upsample, Concat, BN,
+    up-conv/BN/act, 1x1-conv/BN/act; then the final 1x1 conv.  Returns (program, input_id, output_id, tensor-id map)."""
+    P = Program()
+    names = {}
+    zin = P.tensor(input_depth, H, W)
+
+    def scale(i, x):
+        h, w = P.tensors[x]["H"], P.tensors[x]["W"]
+        s = P.tensor(ns[i], *P.conv_out_hw(x, fs, 1)); P.conv(x, s, fs, 1); P.set_bn(s, act=True)
+        d1 = P.tensor(nd[i], *P.conv_out_hw(x, fd, 2)); P.conv(x, d1, fd, 2); P.set_bn(d1, act=True)
+        d2 = P.tensor(nd[i], *P.conv_out_hw(d1, fd, 1)); P.conv(d1, d2, fd, 1); P.set_bn(d2, act=True)
+        deep, kk = d2, nd[i]
+        if i < len(nd) - 1:
+            deep, kk = scale(i + 1, d2), nu[i + 1]
+        cat = P.tensor(ns[i] + kk, h, w); P.concat_up(s, deep, cat); P.set_bn(cat, act=False)
+        u = P.tensor(nu[i], *P.conv_out_hw(cat, fu, 1)); P.conv(cat, u, fu, 1); P.set_bn(u, act=True)
+        u1 = P.tensor(nu[i], h, w); P.conv(u, u1, 1, 1); P.set_bn(u1, act=True)
+        names[i] = dict(skip=s, d1=d1, d2=d2, cat=cat, up=u, up1=u1)
+        return u1
+
+    top = scale(0, zin)
+    out = P.tensor(n_out, H, W); P.conv(top, out, 1, 1)
+    return P, zin, out, names
