@@ -60,7 +60,7 @@ __device__ __forceinline__ float spec_logf(float u)
 __device__ __forceinline__ void spec_boxmuller(uint32_t a, uint32_t b, float& z0, float& z1)
 {
     const float u1 = ((float)(a >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const float rad = __fsqrt_rn(-2.0f * spec_logf(u1));
+    const float rad = __builtin_sqrtf(-2.0f * spec_logf(u1));   // correctly rounded (HIP default); __fsqrt_rn is the native approximation
     const uint32_t t = b >> 8;
     const uint32_t n = (t + 0x200000u) >> 22;
     const int32_t d = (int32_t)t - (int32_t)(n << 22);

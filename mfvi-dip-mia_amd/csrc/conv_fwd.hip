@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(TView in, ConvGeom g, con
     __shared__ __align__(16) float s_w[CC][KK][CT];
     __shared__ ChanFwd s_ch[MFVI_MAX_C];
     __shared__ float s_bias[CT];
-    __shared__ float s_red[4][CT][2];
+    __shared__ double s_red[4][CT][2];
 
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     const int k = blockIdx.z;
@@ -140,9 +140,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(TView in, ConvGeom g, con
     }
 
     // ---- epilogue: bias, store raw output, BN statistics of the output ----
-    float sum[CT], sq[CT];
+    // statistics in double: E[y^2] - E[y]^2 must survive channels whose mean dominates their spread
+    double sum[CT], sq[CT];
 #pragma unroll
-    for (int q = 0; q < CT; ++q) { sum[q] = 0.f; sq[q] = 0.f; }
+    for (int q = 0; q < CT; ++q) { sum[q] = 0.0; sq[q] = 0.0; }
     float* __restrict__ yout = out.data + (long long)k * out.sstride;
     const long long HWo = (long long)g.Ho * g.Wo;
 #pragma unroll
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(TView in, ConvGeom g, con
                 if (co0 + q < Cout) {
                     const float v = acc[p][q] + s_bias[q];
                     yout[(long long)(co0 + q) * HWo + (long long)oy * g.Wo + ox] = v;
-                    sum[q] += v; sq[q] = __builtin_fmaf(v, v, sq[q]);
+                    sum[q] += (double)v; sq[q] += (double)v * (double)v;
                 }
             }
         }
@@ -163,15 +164,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(TView in, ConvGeom g, con
         const int lane = t & 63, wv = t >> 6;
 #pragma unroll
         for (int q = 0; q < CT; ++q) {
-            const float a = wave_sum(sum[q]), b = wave_sum(sq[q]);
+            const double a = wave_sum_d(sum[q]), b = wave_sum_d(sq[q]);
             if (lane == 0) { s_red[wv][q][0] = a; s_red[wv][q][1] = b; }
         }
         __syncthreads();
         if (t < CT * 2) {
             const int q = t >> 1, which = t & 1;
             if (co0 + q < Cout) {
-                const double v = (double)s_red[0][q][which] + (double)s_red[1][q][which] + (double)s_red[2][q][which] +
-                                 (double)s_red[3][q][which];
+                const double v = s_red[0][q][which] + s_red[1][q][which] + s_red[2][q][which] + s_red[3][q][which];
                 atomicAdd(out.stats + ((long long)k * Cout + co0 + q) * 2 + which, v);
             }
         }

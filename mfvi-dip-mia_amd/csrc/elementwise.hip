@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrc s0, FoldSrc s1
     const bool has_bn = x.stats != nullptr;
     const float* __restrict__ yx = x.data + (long long)k * x.sstride + (long long)c * HW;
     float* __restrict__ gout = ga + (long long)k * ga_sstride + (long long)c * HW;
-    float sg = 0.f, sgx = 0.f;
+    double sg = 0.0, sgx = 0.0;
     for (int it = 0; it < EW_ITEMS; ++it) {
         const long long pix = ((long long)blockIdx.x * EW_ITEMS + it) * 256 + t;
         if (pix >= HW) break;
@@ -51,13 +51,13 @@ __global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrc s0, FoldSrc s1
             const float yv = yx[pix];
             const float v = __builtin_fmaf(yv - ch.mean, ch.scale, ch.beta);
             if (x.act && !(v > 0.f)) d *= x.slope;
-            sg += d; sgx = __builtin_fmaf(d, (yv - ch.mean) * ch.rstd, sgx);
+            sg += (double)d; sgx += (double)d * (double)((yv - ch.mean) * ch.rstd);
         }
         gout[pix] = d;
     }
     if (has_bn) {
-        const double a = block_sum_d((double)sg, s_red);
-        const double b = block_sum_d((double)sgx, s_red);
+        const double a = block_sum_d(sg, s_red);
+        const double b = block_sum_d(sgx, s_red);
         if (t == 0) {
             double* o = bsums + ((long long)k * x.C + c) * 2;
             atomicAdd(o, a); atomicAdd(o + 1, b);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, 
     __syncthreads();
     const ChanFwd ch = s_ch;
     float* __restrict__ o = out.data + (long long)k * out.sstride + (long long)c * HW;
-    float sum = 0.f, sq = 0.f;
+    double sum = 0.0, sq = 0.0;
     for (int it = 0; it < EW_ITEMS; ++it) {
         const long long pix = ((long long)blockIdx.x * EW_ITEMS + it) * 256 + t;
         if (pix >= HW) break;
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, 
             const float v10 = apply_fwd(ch, p[y1 * b.W + x0], b.act, b.slope), v11 = apply_fwd(ch, p[y1 * b.W + x1], b.act, b.slope);
             v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
         }
-        o[pix] = v; sum += v; sq = __builtin_fmaf(v, v, sq);
+        o[pix] = v; sum += (double)v; sq += (double)v * (double)v;
     }
     if (out.stats != nullptr) {
-        const double sa = block_sum_d((double)sum, s_red);
-        const double sb = block_sum_d((double)sq, s_red);
+        const double sa = block_sum_d(sum, s_red);
+        const double sb = block_sum_d(sq, s_red);
         if (t == 0) { double* st = out.stats + ((long long)k * Ct + c) * 2; atomicAdd(st, sa); atomicAdd(st + 1, sb); }
     }
 }
@@ -131,10 +131,11 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
     const float* __restrict__ gap = gc.ga + (long long)k * gc.gstride + (long long)c * HW;
     const float* __restrict__ ycp = gc.y + (long long)k * gc.ystride + (long long)c * HW;
     const bool cat_bn = gc.stats != nullptr;
-    float sg = 0.f, sgx = 0.f;
+    double sg = 0.0, sgx = 0.0;
     const TView& dst = from_a ? a : b;
     const int cd = from_a ? c : c - Ca;
     const long long HWd = (long long)dst.H * dst.W;
+    if ((long long)blockIdx.x * EW_ITEMS * 256 >= HWd) return;     // grid is sized for A; B has a quarter of the pixels
     const float* __restrict__ yd = dst.data + (long long)k * dst.sstride + (long long)cd * HWd;
     float* __restrict__ go = (from_a ? ga_a + (long long)k * ga_a_sstride : ga_b + (long long)k * ga_b_sstride) + (long long)cd * HWd;
     for (int it = 0; it < EW_ITEMS; ++it) {
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
             const float yv = yd[pix];
             const float v = __builtin_fmaf(yv - ch.mean, ch.scale, ch.beta);
             if (dst.act && !(v > 0.f)) d *= dst.slope;
-            sg += d; sgx = __builtin_fmaf(d, (yv - ch.mean) * ch.rstd, sgx);
+            sg += (double)d; sgx += (double)d * (double)((yv - ch.mean) * ch.rstd);
         }
         go[pix] = d;
     }
     if (dst.stats != nullptr) {
-        const double sa = block_sum_d((double)sg, s_red);
-        const double sb = block_sum_d((double)sgx, s_red);
+        const double sa = block_sum_d(sg, s_red);
+        const double sb = block_sum_d(sgx, s_red);
         if (t == 0) {
             double* o = (from_a ? bsums_a : bsums_b) + ((long long)k * dst.C + cd) * 2;
             atomicAdd(o, sa); atomicAdd(o + 1, sb);

@@ -53,6 +53,7 @@ def lib():
     L.oracle_net_forward.restype = C.c_void_p
     L.oracle_tape_conv_out.restype = C.c_long
     L.oracle_tape_cat.restype = C.c_long
+    L.oracle_tape_conv_grad.restype = C.c_long
     for name in ("oracle_kl", "oracle_gaussian_nll", "oracle_mse", "oracle_psnr", "oracle_ssim", "oracle_elbo_grad"):
         getattr(L, name).restype = C.c_double
     _lib = L
@@ -211,8 +212,13 @@ class Tape:
         cout = int(conv[conv_id][1])
         y = np.empty(n, np.float32); m = np.zeros(cout, np.float32); r = np.zeros(cout, np.float32)
         lib().oracle_tape_conv_out(self.h, conv_id, _p(y), _p(m), _p(r))
-        hw = n // cout; side = int(round(hw ** 0.5))
-        return y.reshape(cout, side, hw // side), m, r
+        return y.reshape(cout, -1), m, r
+
+    def conv_grad(self, conv_id, which=0):
+        n = lib().oracle_tape_conv_grad(self.h, conv_id, which, None)
+        if n < 0:
+            return None
+        y = np.empty(n, np.float32); lib().oracle_tape_conv_grad(self.h, conv_id, which, _p(y)); return y
 
     def cat(self, scale):
         n = lib().oracle_tape_cat(self.h, scale, None)
