@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): MC-forward-passes/s and ELBO-iterations/s of the MFVI deep-image-prior
+denoising fit, 256x256 skip net, K=16 MC samples per GPU (configs[1]: test_configs/mfvi_den.json values).
+
+One step = one tempered-ELBO iteration: input perturbation, K MC forwards, Gaussian NLL, backward, KL(+grad), Adam
+(and, for N > 1 ranks, the single all-reduce of the flat gradient buffer).  Weak scaling: every rank evaluates its own
+K=16 samples (eps keyed by the global sample index), so the job evaluates 16*N samples per iteration.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Data are synthetic (seeded phantom + noise), weights random-init; inputs are resident
+in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# test_configs/mfvi_den.json:5,9,15-18
+DEN = dict(temp=5.656911698337764e-07, sigma=1.4616642493692077e-05, lr=1e-3, seed=1, p_sigma=0.1, input_depth=16)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
+F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector == FP32-input MFMA peak
+PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd"}
+
+
+def conv_cost(prog, op_index, n_samples):
+    """Algorithmic bytes / FLOPs of one launch of the conv kernels of op `op_index`:
+    input read once + output written once per sample, mu and rho read once; 2*MAC FLOPs."""
+    o = prog.ops[op_index]
+    if o["type"] != 1:
+        return None
+    ti, to = prog.tensors[o["in0"]], prog.tensors[o["out"]]
+    k = o["ksize"]
+    nw = to["C"] * ti["C"] * k * k
+    bytes_ = 4 * n_samples * (ti["C"] * ti["H"] * ti["W"] + to["C"] * to["H"] * to["W"]) + 8 * (nw + to["C"])
+    flops = 2.0 * n_samples * nw * to["H"] * to["W"]
+    return dict(bytes=bytes_, flops=flops, desc="%dx%d conv %d->%d @%dx%d s%d" % (k, k, ti["C"], to["C"], to["H"], to["W"], o["stride"]))
+
+
+def cpu_baseline(size, n_samples=2):
+    """The CPU oracle (oracle/, the restatement of the reference path; kind = "port") timed on the host cores for a
+    bounded sample of the same workload: n_samples MC passes (forward + loss + backward, then KL and one Adam step)."""
+    import numpy as np
+    from oracle import oracle as O
+    net = O.make_net(size, size)
+    mu, rho, bnp = O.init_params(net, DEN["seed"])
+    z = (0.1 * O.uniform_fill(DEN["seed"], 0, 0, 0, 16 * size * size)).reshape(16, size, size)
+    tgt = O.noisy(O.phantom(size, size, DEN["seed"]), DEN["p_sigma"], DEN["seed"])
+    ps = float(np.float32(np.sqrt(DEN["temp"]) * DEN["sigma"] + 1e-6))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = O.set_threads(min(avail, 16))          # the GPU box gives one GPU a 16-core CPU share
+    t0 = time.perf_counter()
+    r = O.elbo_grad(net, mu, rho, bnp, z, tgt, seed=DEN["seed"], step=0, K=n_samples, temp=DEN["temp"], prior_sigma=ps)
+    p = np.concatenate([mu, rho, bnp]); g = np.concatenate([r["dmu"], r["drho"], r["dbn"]])
+    O.adam(p, g, np.zeros_like(p), np.zeros_like(p), DEN["lr"], 1)
+    dt = time.perf_counter() - t0
+    return dict(value=n_samples / dt, unit="MC-forward-passes/s", cores=cores, kind="port",
+                sample="%d MC passes (fwd+NLL+bwd) + KL + Adam of the %dx%d den net, C oracle with OpenMP on %d host threads, %.1f s"
+                       % (n_samples, size, size, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--k", type=int, default=16, help="MC samples per GPU per iteration")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="print the per-kernel time table of one iteration to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)          # "nccl" is RCCL on ROCm
+
+    import mfvi_dip_mia_amd as M
+    from mfvi_dip_mia_amd.engine import ElboEngine
+    M._lib.lib()       # no library, no benchmark: fail loudly
+    from oracle import oracle as O     # synthetic inputs only (phantom + noise); nothing timed comes from the oracle
+
+    S, K = args.size, args.k
+    eng = ElboEngine(S, S, task="den", K=K * world, input_depth=DEN["input_depth"], temp=DEN["temp"], sigma=DEN["sigma"],
+                     lr=DEN["lr"], seed=DEN["seed"], rank=rank, world_size=world, process_group=pg)
+    eng.set_target(torch.from_numpy(O.noisy(O.phantom(S, S, DEN["seed"]), DEN["p_sigma"], DEN["seed"])))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- untimed: warm-up, then one fully instrumented iteration to find the dominant kernel ----
+    for _ in range(args.warmup):
+        eng.step()
+    torch.cuda.synchronize()
+    eng.plan.profile(1)
+    eng.step()
+    torch.cuda.synchronize()
+    recs = eng.plan.profile_read()
+    eng.plan.profile(0)
+    by = {}
+    for op, ps_, ms in recs:
+        by[(op, ps_)] = by.get((op, ps_), 0.0) + ms
+    (dom_op, dom_pass), dom_ms = max(((k_, v) for k_, v in by.items() if k_[1] in (0, 1, 2) and conv_cost(eng.prog, k_[0], 1)), key=lambda kv: kv[1])
+    if args.profile_all and rank == 0:
+        tot = sum(by.values())
+        for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:40]:
+            c = conv_cost(eng.prog, op, eng.chunk)
+            sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else "concat_up"))
+        sys.stderr.write("sum of kernel times in one iteration: %.3f ms\n" % tot)
+
+    # forward-only rate (extra information, untimed region)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(5):
+        eng.forward_only(step=1000 + i)
+    torch.cuda.synchronize(); fwd_only = 5 * eng.K_local * world / (time.perf_counter() - t0)
+
+    # ---- timed region: exactly --steps iterations, only the dominant kernel carries events ----
+    eng.plan.profile(2, dom_op, dom_pass)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    recs = eng.plan.profile_read()
+    eng.plan.profile(0)
+    nll, kl, loss = eng.losses()
+
+    if rank == 0:
+        kms = [ms for _, _, ms in recs]
+        avg_ms = sum(kms) / max(len(kms), 1)
+        cost = conv_cost(eng.prog, dom_op, eng.chunk)
+        ai = cost["flops"] / cost["bytes"]
+        ridge = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if ai >= ridge:      # fp32 arithmetic: above the ridge the matrix/vector fp32 rate bounds the kernel
+            roof = dict(bound="mfma", achieved=cost["flops"] / (avg_ms * 1e-3) / 1e12, peak=F32_PEAK_TFLOPS, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=cost["bytes"] / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof.update(kernel="%s of op %d: %s, %d samples/launch" % (PASS_NAMES[dom_pass], dom_op, cost["desc"], eng.chunk),
+                    avg_launch_ms=avg_ms, launches=len(kms), algorithmic_bytes=cost["bytes"], algorithmic_flops=cost["flops"],
+                    hbm_gbs_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9, hbm_frac_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("kernel_pass") == PASS_NAMES[dom_pass] and tj.get("op") == dom_op:
+                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        total_samples = eng.K_local * world * args.steps
+        res = {
+            "metric": "MC-forward-passes/sec (each inside a full ELBO iteration: fwd+NLL+bwd+KL+Adam), %dx%d skip MFVI denoise" % (S, S),
+            "value": total_samples / dt, "unit": "MC-forward-passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "mfvi_den.json hyper-parameters, %dx%d grayscale, K=%d MC samples per GPU, 26-layer skip net, single fused-HIP path" % (S, S, K),
+                       "mc_samples_per_iteration": eng.K_local * world, "parallelism": "mc-sample sharding x%d, 1 all-reduce/iter" % world},
+            "elbo_iters_per_sec": args.steps / dt, "fwd_only_mc_passes_per_sec": fwd_only,
+            "final_loss": loss, "final_nll": nll, "final_kl": kl,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(S, n_samples=16)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

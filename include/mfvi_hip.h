@@ -85,6 +85,13 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
  * 2: its forward BN sums as doubles [C][2] (dst must hold 2*C doubles). */
 int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tensor_id, int sample, int which, void* dst, void* stream);
 
+/* Optional per-kernel timing with HIP events recorded on the caller's stream around the plan's launches.
+ * mode 0: off; 1: every kernel; 2: only kernel (op, pass).  pass: 0 forward, 1 backward-weight, 2 backward-data,
+ * 3 fold/finalize, 4 concat backward.  mfvi_plan_profile_read synchronises the recorded events, writes up to
+ * `capacity` records (op index, pass, milliseconds) and clears the log. */
+int mfvi_plan_profile(mfvi_plan* plan, int mode, int op, int pass);
+int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* ops, int* passes, float* ms);
+
 /* ---- losses -------------------------------------------------------------------------------------------- */
 /* gaussian_nll (utils/bayesian_utils.py:29-32) for n samples of out[n][2][H][W] against target[H/f][W/f];
  * f > 1 applies the SR projection out[..., ::f, ::f] first (bayesian_optimization.py:2095-2099,2182-2185).

@@ -35,6 +35,8 @@ SIGNATURES = {
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
     "mfvi_backward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mfvi_plan_read_tensor": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "mfvi_plan_profile": (_I, [_P, _I, _I, _I]),
+    "mfvi_plan_profile_read": (_I, [_P, _I, _P, _P, _P, _P]),
     "mfvi_gaussian_nll": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_radon_mse": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "mfvi_radon_forward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

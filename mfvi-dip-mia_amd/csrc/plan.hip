@@ -47,6 +47,11 @@ struct mfvi_plan {
     long long float_base = 0;                  // byte offset of the float arena
     long long total_bytes = 0;
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
+    // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
+    struct Rec { int op, pass; hipEvent_t a, b; };
+    int prof_mode = 0, prof_op = -1, prof_pass = -1;      // 0 off, 1 every kernel, 2 only (prof_op, prof_pass)
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> free_events;
 };
 
 namespace {
@@ -163,6 +168,21 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     return true;
 }
 
+enum { PASS_FWD = 0, PASS_BWD_WEIGHT = 1, PASS_BWD_DATA = 2, PASS_FINALIZE = 3, PASS_CONCAT_BWD = 4 };
+
+struct ProfScope {
+    mfvi_plan* p; hipStream_t st; bool on; hipEvent_t a, b; int op, pass;
+    ProfScope(mfvi_plan* p_, int op_, int pass_, hipStream_t st_) : p(p_), st(st_), on(false), op(op_), pass(pass_)
+    {
+        on = p->prof_mode == 1 || (p->prof_mode == 2 && p->prof_op == op && p->prof_pass == pass);
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!p->free_events.empty()) { e = p->free_events.back(); p->free_events.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(b, st); p->recs.push_back({op, pass, a, b}); } }
+};
+
 struct Ctx {
     const mfvi_plan& p; char* ws; const float* bn; const float* z; int n;
     double* fstats() const { return (double*)ws; }
@@ -225,6 +245,8 @@ int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_
 void mfvi_plan_destroy(mfvi_plan* plan)
 {
     if (!plan) return;
+    for (auto& r : plan->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : plan->free_events) (void)hipEventDestroy(e);
     if (plan->table_dev) (void)hipFree(plan->table_dev);
     delete plan;
 }
@@ -250,6 +272,7 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         od.data = (o.d.out == plan->output) ? out : c.farena() + y.act_off; od.sstride = y.numel;
         od.stats = y.d.has_bn ? c.fstats() + y.stats_off : nullptr;
         int rc;
+        ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV) {
             rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
@@ -280,12 +303,14 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
         if (o.d.type == MFVI_OP_CONV) {
             const GView gy = c.gview(o.d.out, dout);
             const TView xin = c.view(o.d.in0);
-            rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st);
+            { ProfScope ps(plan, i, PASS_BWD_WEIGHT, st);
+              rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st); }
             const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
             if (!rc && need_dx) {
                 const int P = o.g.ks / 2;
                 const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
-                rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st);
+                { ProfScope ps(plan, i, PASS_BWD_DATA, st);
+                  rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
                 const TensorInfo& x = plan->t[o.d.in0];
                 if (!rc && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
                     FoldSrc srcs[2]; int ns = 0;
@@ -296,6 +321,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                         srcs[ns].pad = Pc; ++ns;
                     }
                     float* ga = (o.d.in0 == plan->input) ? dz : c.farena() + x.ga_off;
+                    ProfScope ps(plan, i, PASS_FINALIZE, st);
                     rc = launch_finalize_dx(srcs, ns, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
                 }
             }
@@ -307,6 +333,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                 const TensorInfo& ta = plan->t[o.d.in0];
                 a = c.view(o.d.in0); ga_a = c.farena() + ta.ga_off; sa = ta.numel; bs_a = ta.d.has_bn ? c.bsums() + ta.stats_off : nullptr;
             }
+            ProfScope ps(plan, i, PASS_CONCAT_BWD, st);
             rc = launch_concat_up_bwd(gc, o.d.in0 >= 0 ? &a : nullptr, ga_a, sa, bs_a, c.view(o.d.in1), c.farena() + b.ga_off, b.numel,
                                       b.d.has_bn ? c.bsums() + b.stats_off : nullptr, n_samples, st);
         }
@@ -338,6 +365,31 @@ int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tens
     } else { set_error("read_tensor: bad selector %d", which); return -1; }
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("read_tensor: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int mfvi_plan_profile(mfvi_plan* plan, int mode, int op, int pass)
+{
+    if (!plan || mode < 0 || mode > 2) { set_error("plan_profile: bad arguments"); return -1; }
+    plan->prof_mode = mode; plan->prof_op = op; plan->prof_pass = pass;
+    return 0;
+}
+
+int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* ops, int* passes, float* ms)
+{
+    if (!plan || capacity < 0 || !n_records) { set_error("plan_profile_read: bad arguments"); return -1; }
+    int n = 0;
+    for (auto& r : plan->recs) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+        if (e != hipSuccess) { set_error("plan_profile_read: %s", hipGetErrorString(e)); return (int)e; }
+        if (n < capacity) { ops[n] = r.op; passes[n] = r.pass; ms[n] = t; }
+        ++n;
+        plan->free_events.push_back(r.a); plan->free_events.push_back(r.b);
+    }
+    plan->recs.clear();
+    *n_records = n;      /* may exceed capacity: only the first `capacity` were written */
     return 0;
 }
 

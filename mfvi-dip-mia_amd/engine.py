@@ -1,0 +1,147 @@
+"""Fused tempered-ELBO iteration on one GPU (or one rank of a K-sharded job).
+
+One `step()` is the body of the reference's hot loop (bayesian_optimization.py:1360-1381 for denoising,
+:2176-2191 SR, :568-582 CT) with K Monte-Carlo forwards instead of one (K sequential
+batch-1 forwards on the same perturbed input, loss averaged):
+
+    z      = z0 + 0.1 * N(0,1)                              (RNG domain INPUT, step)
+    out_k  = net_k(z),  k = 0..K-1                          (eps keyed by the GLOBAL sample index)
+    loss   = 1/K sum_k NLL(out_k) + temp * KL
+    grads  -> [all-reduce over ranks when K is sharded] -> Adam
+
+All arithmetic runs in libmfvi_hip; torch only owns the buffers, the stream and (optionally) the process group.
+"""
+import math
+
+from . import _lib as L
+from .program import skip_program
+
+TASK_DEN, TASK_SR, TASK_CT = "den", "sr", "ct"
+
+
+class ElboEngine:
+    def __init__(self, H, W, task=TASK_DEN, K=1, input_depth=16, temp=1.0, sigma=0.1, lr=1e-3, seed=1, sr_factor=4,
+                 theta_deg=None, rank=0, world_size=1, process_group=None, samples_per_launch=None, net_kwargs=None):
+        import torch
+        self.torch = torch
+        self.task, self.K, self.H, self.W = task, int(K), H, W
+        self.rank, self.world = rank, world_size
+        self.pg = process_group
+        if self.K % world_size:
+            raise ValueError("K=%d must be divisible by the number of ranks %d" % (K, world_size))
+        self.K_local = self.K // world_size
+        self.k0 = rank * self.K_local
+        self.temp, self.lr, self.seed = float(temp), float(lr), int(seed)
+        # prior scale exactly as bayesian_optimization.py:1335-1336 + modules/module.py:38, rounded to fp32
+        import numpy as np
+        self.prior_sigma = float(np.float32(math.sqrt(temp) * sigma + 1e-6))
+        n_out = 1 if task == TASK_CT else 2
+        kw = dict(net_kwargs or {})
+        self.prog, self.zin, self.zout, self.names = skip_program(H, W, input_depth, n_out, **kw)
+        self.chunk = min(self.K_local, samples_per_launch or self.K_local)
+        self.plan = self.prog.compile(self.zin, self.zout, self.chunk)
+        P = self.prog
+        self.n_vi, self.n_bn = P.n_vi, P.n_bn
+        self.n_params = 2 * P.n_vi + P.n_bn
+        dev = "cuda"
+        self.params = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_params + 8, dtype=torch.float32, device=dev)     # [+8]: scalars riding the all-reduce
+        self.m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.mu, self.rho, self.bn = self.params[:P.n_vi], self.params[P.n_vi:2 * P.n_vi], self.params[2 * P.n_vi:]
+        self.dmu, self.drho, self.dbn = self.grads[:P.n_vi], self.grads[P.n_vi:2 * P.n_vi], self.grads[2 * P.n_vi:self.n_params]
+        self.z0 = torch.empty((input_depth, H, W), dtype=torch.float32, device=dev)
+        self.z = torch.empty_like(self.z0)
+        self.out = torch.empty((self.chunk, n_out, H, W), dtype=torch.float32, device=dev)
+        self.dout = torch.empty_like(self.out)
+        self.acc = torch.zeros(4, dtype=torch.float64, device=dev)        # [0] nll sum, [1] kl
+        self.sr_factor = sr_factor
+        self.theta = None
+        if task == TASK_CT:
+            th = theta_deg if theta_deg is not None else list(range(0, 180, 4))        # bayesian_optimization.py:545
+            self.theta = torch.tensor(th, dtype=torch.float32, device=dev)
+            self.ct_scratch = torch.empty(self.chunk * len(th) * W, dtype=torch.float32, device=dev)
+        self.t = 0
+        self.target = None
+        self.init_params()
+
+    # -------------------------------------------------------------------------------------------
+    def init_params(self):
+        """mu ~ N(0, 0.1), rho ~ N(-3, 0.1) (BayTorch/modules/module.py:26-30,56-62), BN gamma=1, beta=0;
+        z0 = 0.1*U(0,1) (utils/common_utils.py:134-162).  Drawn from the RNG spec (domain INIT / UNIFORM)."""
+        lib, sp = L.lib(), L.stream_ptr()
+        L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, 0, 0, 0, self.n_vi, 0.0, 0.1, L.ptr(self.mu), sp))
+        L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, 1, 0, 0, self.n_vi, -3.0, 0.1, L.ptr(self.rho), sp))
+        self.bn.zero_()
+        for b in self.prog.bns:
+            self.bn[b["off"]:b["off"] + b["C"]] = 1.0
+        L.check(lib.mfvi_uniform_fill(self.seed, 0, 0, 0, self.z0.numel(), 0.1, L.ptr(self.z0), sp))
+        self.m.zero_(); self.v.zero_(); self.t = 0
+
+    def set_target(self, target):
+        """den: noisy image [H][W]; sr: low-res image [H/f][W/f]; ct: sinogram [T][W]."""
+        self.target = target.contiguous().float().cuda()
+
+    # -------------------------------------------------------------------------------------------
+    def forward_only(self, step=None, perturb=True):
+        """K_local MC forward passes (no loss/backward): the 'MC-forward-passes/s' leg of the metric."""
+        lib, sp = L.lib(), L.stream_ptr()
+        step = self.t if step is None else step
+        if perturb:
+            L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
+        for c0 in range(0, self.K_local, self.chunk):
+            n = min(self.chunk, self.K_local - c0)
+            self.plan.forward(self.mu, self.rho, self.bn, self.z if perturb else self.z0, self.seed, step, self.k0 + c0, n, True, self.out)
+        return self.out
+
+    def _loss_and_dout(self, n):
+        lib, sp = L.lib(), L.stream_ptr()
+        scale = 1.0 / self.K
+        if self.task == TASK_DEN:
+            L.check(lib.mfvi_gaussian_nll(L.ptr(self.out), L.ptr(self.target), n, self.H, self.W, 1, scale, L.ptr(self.dout), L.ptr(self.acc), sp))
+        elif self.task == TASK_SR:
+            L.check(lib.mfvi_gaussian_nll(L.ptr(self.out), L.ptr(self.target), n, self.H, self.W, self.sr_factor, scale, L.ptr(self.dout), L.ptr(self.acc), sp))
+        else:
+            L.check(lib.mfvi_radon_mse(L.ptr(self.out), L.ptr(self.target), L.ptr(self.theta), n, self.H, self.W, self.theta.numel(), scale,
+                                       L.ptr(self.ct_scratch), L.ptr(self.dout), L.ptr(self.acc), sp))
+
+    def grad_only(self, step=None, perturb=True, with_kl=True):
+        """Everything of one iteration except the optimizer update; returns nothing (grads, acc hold the result)."""
+        lib, sp = L.lib(), L.stream_ptr()
+        step = self.t if step is None else step
+        self.grads.zero_(); self.acc.zero_()
+        zsrc = self.z0
+        if perturb:
+            L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
+            zsrc = self.z
+        for c0 in range(0, self.K_local, self.chunk):
+            n = min(self.chunk, self.K_local - c0)
+            self.plan.forward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, True, self.out)
+            self._loss_and_dout(n)
+            self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn, True)
+        if self.world > 1:
+            # the single exchange of the K-sharded step: grads (+ the NLL scalar) summed over ranks
+            self.grads[self.n_params] = self.acc[0].float()
+            self.torch.distributed.all_reduce(self.grads, group=self.pg)
+        if with_kl:
+            # KL and its gradient are deterministic: every rank computes them redundantly (no communication)
+            L.check(lib.mfvi_kl(L.ptr(self.mu), L.ptr(self.rho), self.n_vi, 0.0, self.prior_sigma, L.ptr(self.acc[1:]), sp))
+            L.check(lib.mfvi_kl_backward(L.ptr(self.mu), L.ptr(self.rho), self.n_vi, 0.0, self.prior_sigma, self.temp,
+                                         L.ptr(self.dmu), L.ptr(self.drho), sp))
+
+    def step(self):
+        """One ELBO iteration: K forwards + NLL + backward + (all-reduce) + KL + Adam."""
+        lib, sp = L.lib(), L.stream_ptr()
+        self.grad_only(self.t)
+        self.t += 1
+        L.check(lib.mfvi_adam_step(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_params, self.lr,
+                                   0.9, 0.999, 1e-8, self.t, sp))
+
+    def losses(self):
+        """(nll, kl, loss) of the last grad_only/step — forces a device sync."""
+        if self.world > 1:
+            nll = float(self.grads[self.n_params]) / self.K
+        else:
+            nll = float(self.acc[0]) / self.K
+        kl = float(self.acc[1])
+        return nll, kl, nll + self.temp * kl

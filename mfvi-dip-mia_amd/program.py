@@ -102,6 +102,17 @@ class Plan:
                                       int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(dout), L.ptr(dmu), L.ptr(drho),
                                       L.ptr(dbn), L.ptr(dz), L.stream_ptr()))
 
+    def profile(self, mode, op=-1, pass_=-1):
+        L.check(L.lib().mfvi_plan_profile(self.handle, mode, op, pass_))
+
+    def profile_read(self, capacity=65536):
+        """-> list of (op index, pass, milliseconds) recorded since the last read."""
+        n = C.c_int(0)
+        ops = (C.c_int * capacity)(); passes = (C.c_int * capacity)(); ms = (C.c_float * capacity)()
+        L.check(L.lib().mfvi_plan_profile_read(self.handle, capacity, C.byref(n), ops, passes, ms))
+        k = min(n.value, capacity)
+        return [(ops[i], passes[i], ms[i]) for i in range(k)]
+
     def read_tensor(self, tid, sample=0, which=0):
         import torch
         t = self.prog.tensors[tid]

@@ -68,6 +68,10 @@ def _f(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def set_threads(n=0):
+    return lib().oracle_set_threads(C.c_int(n))
+
+
 # ---- RNG spec ------------------------------------------------------------------------
 def philox(ctr, key):
     c = np.asarray(ctr, dtype=np.uint32); k = np.asarray(key, dtype=np.uint32); o = np.zeros(4, np.uint32)
