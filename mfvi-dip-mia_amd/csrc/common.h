@@ -107,6 +107,15 @@ __device__ __forceinline__ void spec_normal4(const RngKey& key, uint32_t blk, fl
 // torch.nn.functional.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// softplus for the conv kernels' hot weight-sampling loops: hardware exp/log (v_exp_f32 / v_log_f32), with the
+// log1p series where 1 + e would lose e's low bits.  Relative error < 3e-6 (tests/test_gpu_parity.py).
+__device__ __forceinline__ float softplus_fast(float x)
+{
+    if (x > 20.f) return x;
+    const float e = __expf(x);
+    if (e < 0.06f) return e * (1.f - e * (0.5f - e * (0.33333333f - e * (0.25f - e * 0.2f))));
+    return __logf(1.f + e);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Tensor views
@@ -233,6 +242,13 @@ int launch_conv_bwd_data(const GView& gy, const ConvGeom& g, const float* mu, co
                          float* dxp, long long dxp_sstride, int n_samples, hipStream_t st);
 int launch_conv_bwd_weight(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
                            float* dmu, float* drho, int n_samples, hipStream_t st);
+// MFMA variants (conv_mfma.hip): return -2 when the shape is not served and the generic kernel must run.
+int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
+                         OutDesc out, int n_samples, hipStream_t st);
+int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
+                              float* dxp, long long dxp_sstride, int n_samples, hipStream_t st);
+int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
+                                float* dmu, float* drho, int n_samples, hipStream_t st);
 struct FoldSrc { const float* d; long long sstride; int pad; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.
 int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,

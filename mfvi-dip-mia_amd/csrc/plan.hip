@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -222,6 +223,13 @@ bool check_call(const mfvi_plan* p, int n_samples, const void* ws)
     return true;
 }
 
+// MFVI_DISABLE_MFMA=1 forces the generic fp32 VALU kernels (A/B timing and parity cross-checks)
+bool use_mfma()
+{
+    static const bool on = [] { const char* e = getenv("MFVI_DISABLE_MFMA"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 RngKey base_key(uint64_t seed, uint32_t step, uint32_t k0)
 {
     RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = 0; k.sample = k0; k.step = step; return k;
@@ -274,7 +282,8 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         int rc;
         ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV) {
-            rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
+            rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st) : -2;
+            if (rc == -2) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
             rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, n_samples, st);
@@ -304,13 +313,15 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
             const GView gy = c.gview(o.d.out, dout);
             const TView xin = c.view(o.d.in0);
             { ProfScope ps(plan, i, PASS_BWD_WEIGHT, st);
-              rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st); }
+              rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st) : -2;
+              if (rc == -2) rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st); }
             const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
             if (!rc && need_dx) {
                 const int P = o.g.ks / 2;
                 const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
                 { ProfScope ps(plan, i, PASS_BWD_DATA, st);
-                  rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
+                  rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st) : -2;
+                  if (rc == -2) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
                 const TensorInfo& x = plan->t[o.d.in0];
                 if (!rc && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
                     FoldSrc srcs[2]; int ns = 0;
