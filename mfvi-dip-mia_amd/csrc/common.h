@@ -192,6 +192,15 @@ __device__ __forceinline__ int reflect_idx(int i, int n)
     return i;
 }
 
+// Barrier that publishes LDS writes but does NOT drain outstanding global loads: __syncthreads() makes hipcc emit
+// s_waitcnt vmcnt(0) first, which would serialise every register-prefetch behind the barrier (cdna_hip_programming.md §5).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block reductions (256-thread blocks, wave = 64)
 // ------------------------------------------------------------------------------------------------

@@ -8,14 +8,22 @@
 //   MODE 1 (backward-data, stride 1):            m = cin,  k = (cout, flipped tap), B = zero-padded dy (formed on
 //                                                 load from ga / y / BN sums), output = gradient wrt the PADDED input
 //
-// Per 256-thread block: a 32 x TH pixel tile x (16*MF) output channels.  Per reduction chunk of CC channels the block
-// stages the activation tile (deferred BN + LeakyReLU, reflection in the index math) and SAMPLES the weight slab
-// w = mu + softplus(rho)*eps into LDS (eps from Philox, never stored); each of the 4 waves then owns TH/4 rows =
-// NF = TH/2 pixel fragments and issues MF*NF MFMAs per (tap, 4-channel) step from conflict-free ds_read_b32:
+// Per 256-thread block: 32 x TH pixel tiles x (16*MF) output channels.  The block SAMPLES its weight slab
+// w = mu + softplus(rho)*eps into LDS (eps from Philox, never stored in HBM) —
+//   WS = true  (weight-stationary): the whole slab [taps][all reduction channels][16*MF] once, then it walks several
+//               pixel tiles, so every sampled weight is reused by thousands of pixels (high-resolution layers);
+//   WS = false: one CC-channel chunk at a time inside the reduction loop (slabs too big for LDS / few tiles).
+// Activation tiles stream through LDS in CC-channel chunks (deferred BN + LeakyReLU applied on the way, reflection in
+// the index math); the next chunk's global loads are issued into registers before the MFMA loop of the current one.
+// Each of the 4 waves owns TH/4 rows = NF = TH/2 pixel fragments and issues MF*NF MFMAs per (tap, 4-channel) step from
+// conflict-free ds_read_b32:
 //   activations  s_x[k][row][col], plane pitch == 16 (mod 32) floats  -> lanes 0-15 / 16-31 of a half-wave hit disjoint banks
 //   weights      s_w[tap][k][m],   row pitch   == 16 (mod 32) floats
 // Epilogue (MODE 0): + sampled bias, raw store, per-channel sum / sum^2 of the BatchNorm that follows (fp64 atomics).
 #include "common.h"
+#include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -27,7 +35,7 @@ template <int KS, int STRIDE, int MF, int TH>
 struct MCfg {
     static constexpr int TW = 32;
     static constexpr int CT = 16 * MF;
-    static constexpr int CC = 8;                                   // reduction channels per stage
+    static constexpr int CC = 8;                                   // reduction channels per activation stage
     static constexpr int NF = TH / 2;                              // pixel fragments per wave (TH/4 rows x 2 halves)
     static constexpr int KK = KS * KS;
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
@@ -36,47 +44,61 @@ struct MCfg {
     static constexpr int PLANE = pitch16(IN_TH * PITCH);           // == 16 (mod 32)
     static constexpr int CTP = pitch16(CT);                        // == 16 (mod 32)
     static constexpr int X_FLOATS = CC * PLANE;
-    static constexpr int W_FLOATS = KK * CC * CTP;
 };
 
 static_assert(pitch16(16) == 16 && pitch16(32) == 48 && pitch16(64) == 80 && pitch16(340) % 32 == 16, "pitch16");
 
-template <int KS, int STRIDE, int MF, int TH, int MODE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(TView xin, GView gin, ConvGeom g, const float* __restrict__ mu,
-                                                        const float* __restrict__ rho, RngKey key, int sample_weights,
-                                                        OutDesc out, float* __restrict__ dxp, long long dxp_sstride,
-                                                        int tiles_x)
+struct MfmaArgs {
+    TView xin; GView gin; ConvGeom g;
+    const float* mu; const float* rho;
+    RngKey key; int sample_weights;
+    OutDesc out; float* dxp; long long dxp_sstride;
+    int tiles_x, n_tiles, tiles_per_block;
+    int dbg;      // MFVI_DBG bit mask (experiments only): 1 skip global loads, 2 skip MFMA, 4 skip LDS stores, 8 skip epilogue
+};
+
+template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS>
+__global__ __launch_bounds__(512, (MF == 1 ? 4 : 2)) void conv_mfma_kernel(MfmaArgs A)
 {
     using Cfg = MCfg<KS, STRIDE, MF, TH>;
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
+    constexpr int WCHUNK = KK * CC * CTP;               // floats of one weight chunk (non-WS double buffer)
     static_assert(MODE == 0 || STRIDE == 1, "backward-data on the MFMA path is stride 1 only");
 
-    __shared__ float s_x[Cfg::X_FLOATS];
-    __shared__ float s_w[Cfg::W_FLOATS];
-    __shared__ float s_chf[MFVI_MAX_C * 4];          // ChanFwd (MODE 0) / ChanBwd c1..c3,mean,rstd packed (MODE 1 uses s_chb)
+    // Wave specialisation: waves 0-3 (consumers) only issue MFMAs; waves 4-7 (producers) stream the next activation
+    // chunk (global loads -> deferred BN/LeakyReLU or BN-backward -> LDS) and sample the next weight chunk into the
+    // other half of a double buffer.  One barrier per chunk; VALU/VMEM work hides under the matrix pipe.
+    extern __shared__ __align__(16) float s_w[];          // WS: [KK][REDP][CTP]; else 2 x [KK][CC][CTP]
+    __shared__ float s_x[2][Cfg::X_FLOATS];
+    __shared__ ChanFwd s_ch[MODE == 0 ? MFVI_MAX_C : 1];
     __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
     __shared__ double s_red[4][CT][2];
 
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const ConvGeom& g = A.g;
+    const float* __restrict__ mu = A.mu; const float* __restrict__ rho = A.rho;
+    const int sample_weights = A.sample_weights;
+    const int tid = threadIdx.x;
+    const bool producer = tid >= 256;
+    const int t = tid & 255, lane = t & 63, wv = t >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int k = blockIdx.z;
     const int m0 = blockIdx.y * CT;                                  // first output channel of the block
-    const int px0 = (blockIdx.x % tiles_x) * TW, py0 = (blockIdx.x / tiles_x) * TH;
 
     // MODE 0: reduce over cin, outputs = cout.   MODE 1: reduce over cout, outputs = cin.
-    const int RED = MODE == 0 ? g.Cin : g.Cout;                      // reduction channels
-    const int MOUT = MODE == 0 ? g.Cout : g.Cin;                     // output channels
+    const int RED = MODE == 0 ? g.Cin : g.Cout;
+    const int MOUT = MODE == 0 ? g.Cout : g.Cin;
     const int mt = min(CT, MOUT - m0);
+    const int REDP = WS ? ((RED + 3) & ~3) : CC;                     // reduction-channel pitch of s_w
+    const int n_chunks = (RED + CC - 1) / CC;
 
-    RngKey kw = key; kw.sample += (uint32_t)k; kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * g.layer_id);
+    RngKey kw = A.key; kw.sample += (uint32_t)k; kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * g.layer_id);
 
-    ChanFwd* s_ch = reinterpret_cast<ChanFwd*>(s_chf);
     if (MODE == 0) {
-        for (int c = t; c < g.Cin; c += 256) s_ch[c] = chan_fwd(xin, k, c);
-        if (t < CT) {
-            const int co = m0 + t; float b = 0.f;
+        for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c);
+        if (tid < CT) {
+            const int co = m0 + tid; float b = 0.f;
             if (co < g.Cout && g.b_off >= 0) {
                 b = mu[g.b_off + co];
                 if (sample_weights) {
@@ -85,257 +107,329 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(TView xin, GView gin, Co
                     b += softplus_f(rho[g.b_off + co]) * z[co & 3];
                 }
             }
-            s_bias[t] = b;
+            s_bias[tid] = b;
         }
     } else {
-        for (int c = t; c < g.Cout; c += 256) s_chb[c] = chan_bwd(gin, k, c);
+        for (int c = tid; c < g.Cout; c += 512) s_chb[c] = chan_bwd(A.gin, k, c);
     }
 
-    f32x4 acc[MF][NF];
+    // Sample the weight slab of reduction channels [c0, c0+cc) into wdst[tap][kbase + kk][m] with `nthr` threads.
+    //   MODE 0: rows = output channel m, global range ((m0+m)*Cin + c0)*KK + [0, cc*KK),   element -> (kk, tap)
+    //   MODE 1: rows = reduction channel kk, range ((c0+kk)*Cin + m0)*KK + [0, mt*KK),     element -> (m, flipped tap)
+    // The launcher guarantees Cin % 4 == 0 and w_off % 4 == 0, so every row range is a whole number of aligned Philox
+    // blocks (4 consecutive weights): one float4 of mu, one of rho and one Philox call per block.
+    auto sample_slab = [&](int c0, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
+        const int rows = MODE == 0 ? CT : cc4;
+        const int valid_rows = MODE == 0 ? mt : cc;
+        const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
+        const float4* __restrict__ mu4 = reinterpret_cast<const float4*>(mu + g.w_off);
+        const float4* __restrict__ rho4 = reinterpret_cast<const float4*>(rho + g.w_off);
+        for (int idx = th; idx < rows * G; idx += nthr) {
+            const int row = idx / G, gi = idx - row * G;
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < valid_rows) {
+                const int blk = (MODE == 0 ? (((m0 + row) * g.Cin + c0) * KK) : (((c0 + row) * g.Cin + m0) * KK)) / 4 + gi;
+                const float4 a = mu4[blk];
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                if (sample_weights) {
+                    const float4 b = rho4[blk];
+                    float z[4]; spec_normal4(kw, (uint32_t)blk, z);
+                    w[0] = __builtin_fmaf(softplus_fast(b.x), z[0], w[0]); w[1] = __builtin_fmaf(softplus_fast(b.y), z[1], w[1]);
+                    w[2] = __builtin_fmaf(softplus_fast(b.z), z[2], w[2]); w[3] = __builtin_fmaf(softplus_fast(b.w), z[3], w[3]);
+                }
+            }
 #pragma unroll
-    for (int a = 0; a < MF; ++a)
-#pragma unroll
-        for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // source tile geometry
-    const int H = g.H, W = g.W;
-    const float* __restrict__ xsrc = MODE == 0 ? xin.data + (long long)k * xin.sstride : gin.ga + (long long)k * gin.gstride;
-    const float* __restrict__ ysrc = (MODE == 1 && gin.y) ? gin.y + (long long)k * gin.ystride : nullptr;
-    const int SH = MODE == 0 ? H : g.Ho, SW = MODE == 0 ? W : g.Wo;          // source plane size
-    const int SHW = SH * SW;
-    const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);          // tile origin in source coordinates
-    const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (KS - 1);
-
-    // Each thread owns NPOS fixed positions of the staged tile; their global / LDS offsets never change.
-    constexpr int NPOS = (IN_TH * IN_TW + 255) / 256;
-    int goff[NPOS], loff[NPOS];
-#pragma unroll
-    for (int j = 0; j < NPOS; ++j) {
-        const int p = t + 256 * j;
-        const int iy = p / IN_TW, ix = p - iy * IN_TW;
-        loff[j] = p < IN_TH * IN_TW ? iy * PITCH + ix : -1;
-        int gy = sy0 + iy, gx = sx0 + ix;
-        if (MODE == 0) {
-            gy = reflect_idx(gy, H); gx = reflect_idx(gx, W);
-            gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1);       // tile overhang: masked at the store
-            goff[j] = gy * W + gx;
-        } else {
-            goff[j] = (gy >= 0 && gy < SH && gx >= 0 && gx < SW) ? gy * SW + gx : -1;   // zero padding
+            for (int l = 0; l < 4; ++l) {
+                const int rel = gi * 4 + l, q = rel / KK, tap = rel - q * KK;
+                if (MODE == 0) wdst[(tap * REDP + kbase + q) * CTP + row] = w[l];
+                else wdst[((KK - 1 - tap) * REDP + kbase + row) * CTP + q] = w[l];
+            }
         }
-        if (loff[j] < 0) goff[j] = -1;
-    }
-    float xr[NPOS][CC], yr[MODE == 1 ? NPOS : 1][MODE == 1 ? CC : 1];
-
-    auto prefetch = [&](int c0) {            // global loads of chunk c0 into registers; nothing waits on them here
-        const int cc = min(CC, RED - c0);
-#pragma unroll
-        for (int j = 0; j < NPOS; ++j)
-#pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                const bool ok = goff[j] >= 0 && c < cc;
-                const long long off = (long long)(c0 + c) * SHW + goff[j];
-                xr[j][c] = ok ? xsrc[off] : 0.f;
-                if (MODE == 1) yr[j][c] = (ok && ysrc) ? ysrc[off] : 0.f;
+        if (MODE == 0 && cc4 > cc)       // pad the last 4-channel step with zero weights
+            for (int idx = th; idx < (cc4 - cc) * KK * CT; idx += nthr) {
+                const int m = idx % CT, r = idx / CT, kk = cc + r % (cc4 - cc), tap = r / (cc4 - cc);
+                wdst[(tap * REDP + kbase + kk) * CTP + m] = 0.f;
+            }
+        if (MODE == 1 && mt < CT)        // output channels beyond the tensor: keep the (unstored) accumulators finite
+            for (int idx = th; idx < KK * cc4 * (CT - mt); idx += nthr) {
+                const int m = mt + idx % (CT - mt), r = idx / (CT - mt), kk = r % cc4, tap = r / cc4;
+                wdst[(tap * REDP + kbase + kk) * CTP + m] = 0.f;
             }
     };
 
-    // this wave's fragments: rows wv*(TH/4) .. +TH/4-1, two 16-pixel halves each
-    int boff[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
-        boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE;
-    }
-    const int aoff = l4 * CTP + l15;
-    const bool w_aligned = (g.w_off & 3) == 0;
+    const int tile_begin = blockIdx.x * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
+    if (tile_begin >= tile_end) return;
+    const int n_iters = (tile_end - tile_begin) * n_chunks;
 
-    prefetch(0);
-    for (int c0 = 0; c0 < RED; c0 += CC) {
-        __syncthreads();                       // every wave is done reading the previous chunk
-        const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
-        // ---- registers -> LDS: deferred BN/LeakyReLU (MODE 0) or BN-backward (MODE 1) ----
+    if (WS)       // the whole slab, once, by all 8 waves
+        for (int c0 = 0; c0 < RED; c0 += CC) { const int cc = min(CC, RED - c0); sample_slab(c0, cc, (cc + 3) & ~3, c0, s_w, tid, 512); }
+
+    const int H = g.H, W = g.W;
+    const int SH = MODE == 0 ? H : g.Ho, SW = MODE == 0 ? W : g.Wo;
+    const int SHW = SH * SW;
+
+    if (producer) {
+        // ======================= producer waves =======================
+        const float* __restrict__ xsrc = MODE == 0 ? A.xin.data + (long long)k * A.xin.sstride : A.gin.ga + (long long)k * A.gin.gstride;
+        const float* __restrict__ ysrc = (MODE == 1 && A.gin.y) ? A.gin.y + (long long)k * A.gin.ystride : nullptr;
+        const int xact = A.xin.act; const float xslope = A.xin.slope;
+        constexpr int NPOS = (IN_TH * IN_TW + 255) / 256;       // fixed positions of the staged tile owned by this thread
+        int goff[NPOS], loff[NPOS];
 #pragma unroll
         for (int j = 0; j < NPOS; ++j) {
-            if (loff[j] < 0) continue;
-#pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                if (c >= cc4) break;
-                float v = 0.f;
-                if (c < cc) {
-                    if (MODE == 0) v = apply_fwd(s_ch[c0 + c], xr[j][c], xin.act, xin.slope);
-                    else v = goff[j] < 0 ? 0.f : (ysrc ? apply_bwd(s_chb[c0 + c], xr[j][c], yr[j][c]) : xr[j][c]);
-                }
-                s_x[c * PLANE + loff[j]] = v;
-            }
+            const int p = t + 256 * j, iy = p / IN_TW, ix = p - iy * IN_TW;
+            loff[j] = p < IN_TH * IN_TW ? iy * PITCH + ix : -1;
         }
-        // ---- sample the weight slab into s_w[tap][kk][m] ----
-        {
-            // MODE 0: rows = output channel m, row range ((m0+m)*Cin + c0)*KK + [0, cc*KK),   element -> (kk, tap)
-            // MODE 1: rows = reduction channel kk, range ((c0+kk)*Cin + m0)*KK + [0, mt*KK),  element -> (m, flipped tap)
-            const int rows = MODE == 0 ? CT : cc4;
-            const int valid_rows = MODE == 0 ? mt : cc;
-            const int len = (MODE == 0 ? cc : mt) * KK, G = (len >> 2) + 2;
-            for (int idx = t; idx < rows * G; idx += 256) {
-                const int row = idx / G, gi = idx - row * G;
-                if (row < valid_rows) {
-                    const long long j0 = MODE == 0 ? ((long long)(m0 + row) * g.Cin + c0) * KK : ((long long)(c0 + row) * g.Cin + m0) * KK;
-                    const long long blk = (j0 >> 2) + gi, jb = blk << 2;
-                    if (jb < j0 + len) {
-                        float mv[4], rv[4];
-                        if (w_aligned && jb >= j0 && jb + 4 <= j0 + len) {
-                            const float4 a = *reinterpret_cast<const float4*>(mu + g.w_off + jb);
-                            mv[0] = a.x; mv[1] = a.y; mv[2] = a.z; mv[3] = a.w;
-                            if (sample_weights) { const float4 b = *reinterpret_cast<const float4*>(rho + g.w_off + jb); rv[0] = b.x; rv[1] = b.y; rv[2] = b.z; rv[3] = b.w; }
-                        } else {
+        auto set_tile = [&](int tile) {
+            const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+            const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
+            const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (KS - 1);
 #pragma unroll
-                            for (int l = 0; l < 4; ++l) {
-                                const long long j = jb + l; const bool in = j >= j0 && j < j0 + len;
-                                mv[l] = in ? mu[g.w_off + j] : 0.f; rv[l] = (in && sample_weights) ? rho[g.w_off + j] : 0.f;
-                            }
-                        }
-                        float z[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (sample_weights) spec_normal4(kw, (uint32_t)blk, z);
-#pragma unroll
-                        for (int l = 0; l < 4; ++l) {
-                            const long long j = jb + l;
-                            if (j >= j0 && j < j0 + len) {
-                                const int rel = (int)(j - j0), q = rel / KK, tap = rel - q * KK;
-                                const float w = sample_weights ? __builtin_fmaf(softplus_fast(rv[l]), z[l], mv[l]) : mv[l];
-                                if (MODE == 0) s_w[(tap * CC + q) * CTP + row] = w;
-                                else s_w[((KK - 1 - tap) * CC + row) * CTP + q] = w;
-                            }
-                        }
-                    }
+            for (int j = 0; j < NPOS; ++j) {
+                const int p = t + 256 * j, iy = p / IN_TW, ix = p - iy * IN_TW;
+                int gy = sy0 + iy, gx = sx0 + ix;
+                if (MODE == 0) {
+                    gy = reflect_idx(gy, H); gx = reflect_idx(gx, W);
+                    gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1);       // tile overhang: masked at the store
+                    goff[j] = gy * W + gx;
                 } else {
+                    goff[j] = (gy >= 0 && gy < SH && gx >= 0 && gx < SW) ? gy * SW + gx : -1;   // zero padding
+                }
+                if (loff[j] < 0) goff[j] = -1;
+            }
+        };
+        float xr[NPOS][CC], yr[MODE == 1 ? NPOS : 1][MODE == 1 ? CC : 1];
+        unsigned okmask = 0;
+        // Branch-free: every load uses a valid (clamped) address; invalid positions / channels are zeroed at the LDS store.
+        auto prefetch = [&](int c0) {
+            okmask = 0;
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) {
-                        const int rel = gi * 4 + l;
-                        if (rel < len) {
-                            const int q = rel / KK, tap = rel - q * KK;
-                            if (MODE == 0) s_w[(tap * CC + q) * CTP + row] = 0.f; else s_w[(tap * CC + row) * CTP + q] = 0.f;
-                        }
-                    }
+            for (int j = 0; j < NPOS; ++j) {
+                if (goff[j] >= 0) okmask |= 1u << j;
+                const int gsafe = max(goff[j], 0);
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const int off = min(c0 + c, RED - 1) * SHW + gsafe;
+                    xr[j][c] = (A.dbg & 1) ? 1.0f : xsrc[off];
+                    if (MODE == 1) yr[j][c] = ysrc ? ysrc[off] : 0.f;
                 }
             }
-            if (MODE == 0 && cc4 > cc)       // pad the last 4-channel step with zero weights
-                for (int idx = t; idx < (cc4 - cc) * KK * CT; idx += 256) {
-                    const int m = idx % CT, r = idx / CT, kk = cc + r % (cc4 - cc), tap = r / (cc4 - cc);
-                    s_w[(tap * CC + kk) * CTP + m] = 0.f;
+        };
+        auto store = [&](int c0, float* __restrict__ dst) {      // registers -> LDS with the deferred transform
+            const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
+#pragma unroll
+            for (int j = 0; j < NPOS; ++j) {
+                if (loff[j] < 0) continue;
+                const bool okj = (okmask >> j) & 1u;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    float v = 0.f;
+                    if (MODE == 0) v = apply_fwd(s_ch[min(c0 + c, RED - 1)], xr[j][c], xact, xslope);
+                    else v = ysrc ? apply_bwd(s_chb[min(c0 + c, RED - 1)], xr[j][c], yr[j][c]) : xr[j][c];
+                    if (c >= cc || (MODE == 1 && !okj)) v = 0.f;
+                    if (c < cc4 && !(A.dbg & 4)) dst[c * PLANE + loff[j]] = v;
                 }
-            if (MODE == 1 && mt < CT)        // output channels beyond the tensor: keep the (unstored) accumulators finite
-                for (int idx = t; idx < KK * cc4 * (CT - mt); idx += 256) {
-                    const int m = mt + idx % (CT - mt), r = idx / (CT - mt), kk = r % cc4, tap = r / cc4;
-                    s_w[(tap * CC + kk) * CTP + m] = 0.f;
-                }
+            }
+        };
+        auto chunk_of = [&](int it, int& tile, int& c0) { tile = tile_begin + it / n_chunks; c0 = (it % n_chunks) * CC; };
+
+        int ptile, pc0;
+        chunk_of(0, ptile, pc0);
+        set_tile(ptile); prefetch(pc0);
+        __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
+        store(pc0, s_x[0]);
+        if (!WS) { const int cc = min(CC, RED - pc0); sample_slab(pc0, cc, (cc + 3) & ~3, 0, s_w, t, 256); }
+        if (n_iters > 1) { int nt, nc; chunk_of(1, nt, nc); if (nt != ptile) { set_tile(nt); ptile = nt; } prefetch(nc); }
+        lds_barrier();                                    // (A) chunk 0 published
+        for (int it = 0; it < n_iters; ++it) {
+            if (it + 1 < n_iters) {
+                int nt, nc; chunk_of(it + 1, nt, nc);
+                store(nc, s_x[(it + 1) & 1]);
+                if (!WS) { const int cc = min(CC, RED - nc); sample_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
+                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
+            }
+            lds_barrier();
         }
-        __syncthreads();
-        if (c0 + CC < RED) prefetch(c0 + CC);          // next chunk's loads fly while the matrix cores work
-        // ---- MFMA ----
-        const int steps = cc4 >> 2;
+        if (MODE == 0 && A.out.stats != nullptr) __syncthreads();        // (Z) consumers publish their BN partial sums
+    } else {
+        // ======================= consumer waves =======================
+        int boff[NF];
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+        for (int f = 0; f < NF; ++f) {
+            const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
+            boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE;
+        }
+        const int aoff = l4 * CTP + l15;
+        const int wtap = REDP * CTP;
+        f32x4 acc[MF][NF];
+        double ssum[MF][4], ssq[MF][4];        // BN statistics of this wave's outputs, accumulated over all tiles of the block
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const int tap = ky * KS + kx;
-                for (int s = 0; s < steps; ++s) {
-                    float a[MF], b[NF];
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int i = 0; i < MF; ++i) a[i] = s_w[(tap * CC + s * 4) * CTP + aoff + i * 16];
+            for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.0; ssq[i][r] = 0.0; }
+        __syncthreads();                                  // (S0)
+        lds_barrier();                                    // (A)
+        for (int it = 0; it < n_iters; ++it) {
+            const int tile = tile_begin + it / n_chunks, ci = it % n_chunks, c0 = ci * CC;
+            const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
+            if (ci == 0) {
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) b[f] = s_x[s * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                for (int a = 0; a < MF; ++a)
+#pragma unroll
+                    for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            // ---- MFMA: fully unrolled k-steps (tap x 4-channel step), operand fragments double-buffered in registers
+            //      so the LDS reads of step q+1 are in flight while the matrix core runs step q ----
+            const float* __restrict__ sx = s_x[it & 1];
+            const float* __restrict__ wq = (WS ? s_w + c0 * CTP : s_w + (it & 1) * WCHUNK) + aoff;
+            auto run = [&](auto steps_c) {
+                constexpr int STEPS = decltype(steps_c)::value, NQ = KK * STEPS;
+                float a[2][MF], b[2][NF];
+                auto load = [&](int q, float (&aa)[MF], float (&bb)[NF]) {
+                    const int tap = q / STEPS, st_ = q % STEPS, ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + st_ * 4 * CTP + i * 16];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) bb[f] = sx[st_ * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                };
+                load(0, a[0], b[0]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + 1 < NQ) load(q + 1, a[(q + 1) & 1], b[(q + 1) & 1]);
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
                         for (int f = 0; f < NF; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[f], acc[i][f], 0, 0, 0);
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][i], b[q & 1][f], acc[i][f], 0, 0, 0);
                 }
-            }
-    }
+            };
+            if (!(A.dbg & 2)) { if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{}); }
 
-    // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg
-    if (MODE == 0) {
-        float* __restrict__ yout = out.data + (long long)k * out.sstride;
-        const long long HWo = (long long)g.Ho * g.Wo;
+            if (ci == n_chunks - 1 && !(A.dbg & 8)) {
+                // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg
+                const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+                if (MODE == 0) {
+                    float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride;
+                    const int HWo = g.Ho * g.Wo;
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            double sum[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < MF; ++i) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int oy = py0 + wv * (TH / 4) + (f >> 1), ox = px0 + (f & 1) * 16 + l15;
-                if (oy < g.Ho && ox < g.Wo) {
+                        for (int f = 0; f < NF; ++f) {
+                            const int oy = py0 + wv * (TH / 4) + (f >> 1), ox = px0 + (f & 1) * 16 + l15;
+                            if (oy < g.Ho && ox < g.Wo) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ml = i * 16 + l4 * 4 + r;
-                        if (ml < mt) {
-                            const float v = acc[i][f][r] + s_bias[ml];
-                            yout[(long long)(m0 + ml) * HWo + (long long)oy * g.Wo + ox] = v;
-                            sum[r] += (double)v; sq[r] += (double)v * (double)v;
+                                for (int r = 0; r < 4; ++r) {
+                                    const int ml = i * 16 + l4 * 4 + r;
+                                    if (ml < mt) {
+                                        const float v = acc[i][f][r] + s_bias[ml];
+                                        yout[(long long)(m0 + ml) * HWo + oy * g.Wo + ox] = v;
+                                        ssum[i][r] += (double)v; ssq[i][r] += (double)v * (double)v;
+                                    }
+                                }
+                            }
                         }
                     }
+                } else {
+                    const int Hp = g.H + 2 * P, Wp = g.W + 2 * P;
+                    float* __restrict__ o = A.dxp + (long long)k * A.dxp_sstride;
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const int pr = py0 + wv * (TH / 4) + (f >> 1), pc = px0 + (f & 1) * 16 + l15;
+                            if (pr < Hp && pc < Wp) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int ml = i * 16 + l4 * 4 + r;
+                                    if (ml < mt) o[(long long)(m0 + ml) * Hp * Wp + pr * Wp + pc] = acc[i][f][r];
+                                }
+                            }
+                        }
                 }
             }
-            if (out.stats != nullptr) {
+            lds_barrier();
+        }
+        if (MODE == 0 && A.out.stats != nullptr) {
+            // One fp64 atomic per (channel, moment) per BLOCK: same-address float atomics serialise at the memory side
+            // (~0.2 us each), so per-tile or per-wave atomics would dominate the kernel.
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double a = sum[r], b = sq[r];
+                    double a = ssum[i][r], b = ssq[i][r];
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
                     if (l15 == 0) { s_red[wv][i * 16 + l4 * 4 + r][0] = a; s_red[wv][i * 16 + l4 * 4 + r][1] = b; }
                 }
-            }
-        }
-        if (out.stats != nullptr) {
-            __syncthreads();
+            __syncthreads();                              // (Z)
             if (t < CT * 2) {
                 const int q = t >> 1, which = t & 1;
                 if (q < mt)
-                    atomicAdd(out.stats + ((long long)k * g.Cout + m0 + q) * 2 + which,
+                    atomicAdd(A.out.stats + ((long long)k * g.Cout + m0 + q) * 2 + which,
                               s_red[0][q][which] + s_red[1][q][which] + s_red[2][q][which] + s_red[3][q][which]);
             }
         }
-    } else {
-        const int Hp = g.H + 2 * P, Wp = g.W + 2 * P;
-        float* __restrict__ o = dxp + (long long)k * dxp_sstride;
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int pr = py0 + wv * (TH / 4) + (f >> 1), pc = px0 + (f & 1) * 16 + l15;
-                if (pr < Hp && pc < Wp) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ml = i * 16 + l4 * 4 + r;
-                        if (ml < mt) o[(long long)(m0 + ml) * Hp * Wp + (long long)pr * Wp + pc] = acc[i][f][r];
-                    }
-                }
-            }
     }
 }
+
+struct Tune { int mf = 0, th = 0, T = 0, blocks = 512; };
+const Tune& tune()
+{
+    static const Tune t = [] { Tune v; const char* e = getenv("MFVI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &v.mf, &v.th, &v.T, &v.blocks); if (v.blocks < 1) v.blocks = 512; return v; }();
+    return t;
+}
+inline int tune_mf() { return tune().mf; }
+inline int tune_th() { return tune().th; }
+inline int tune_T() { return tune().T; }
+inline int tune_blocks() { return tune().blocks; }
 
 template <int KS, int STRIDE, int MODE>
 int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const float* mu, const float* rho, RngKey key,
                    int sample_weights, OutDesc out, float* dxp, long long dxp_sstride, int n_samples, hipStream_t st)
 {
-    const int P = g.ks / 2;
+    const int P = g.ks / 2, KK = KS * KS;
     const int OH = MODE == 0 ? g.Ho : g.H + 2 * P, OW = MODE == 0 ? g.Wo : g.W + 2 * P;    // output pixel domain
-    const int MOUT = MODE == 0 ? g.Cout : g.Cin;
+    const int MOUT = MODE == 0 ? g.Cout : g.Cin, RED = MODE == 0 ? g.Cin : g.Cout;
+    const int RED4 = (RED + 3) & ~3;
+    static const int dbg = [] { const char* e = getenv("MFVI_DBG"); return e ? atoi(e) : 0; }();
+    MfmaArgs A{xin, gin, g, mu, rho, key, sample_weights, out, dxp, dxp_sstride, 0, 0, 1, dbg};
+
+    // Pick the largest tile that still gives the chip enough blocks: big tiles amortise the in-kernel weight sampling
+    // (each sampled weight is reused by every pixel of the tile), small ones keep 256 CUs busy.  When the whole slab of a
+    // block fits in LDS and there are tiles to spare, go weight-stationary and give each block several tiles.
+    const auto blocks = [&](int mf, int th) { return (long long)((OW + 31) / 32) * ((OH + th - 1) / th) * ((MOUT + 16 * mf - 1) / (16 * mf)) * n_samples; };
+    // fewest padded output channels first (36 -> 3x16, not 2x32), larger fragments on ties
+    const auto padded = [&](int mf) { return ((MOUT + 16 * mf - 1) / (16 * mf)) * mf; };
+    const int mf_max = padded(4) <= padded(2) && padded(4) <= padded(1) ? 4 : (padded(2) <= padded(1) ? 2 : 1);
+    const long long want = 768;
 #define GO(MF_, TH_)                                                                                                       \
     {                                                                                                                      \
-        const int tiles_x = (OW + 31) / 32, tiles_y = (OH + TH_ - 1) / TH_;                                                \
-        dim3 grid(tiles_x * tiles_y, (MOUT + 16 * MF_ - 1) / (16 * MF_), n_samples);                                       \
-        hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE>), grid, dim3(256), 0, st, xin, gin, g, mu, rho, key, \
-                           sample_weights, out, dxp, dxp_sstride, tiles_x);                                                \
+        using Cfg = MCfg<KS, STRIDE, MF_, TH_>;                                                                            \
+        A.tiles_x = (OW + 31) / 32;                                                                                        \
+        A.n_tiles = A.tiles_x * ((OH + TH_ - 1) / TH_);                                                                    \
+        const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
+        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP, ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * Cfg::CTP; \
+        const long long nb = (long long)A.n_tiles * my * n_samples;                                                        \
+        int T = (int)(nb / tune_blocks()); T = T < 1 ? 1 : (T > 8 ? 8 : T);                                                \
+        if (tune_T() > 0) T = tune_T();                                                                                    \
+        if (T >= 2 && ws_bytes <= 40 * 1024) {                                                                             \
+            A.tiles_per_block = T;                                                                                         \
+            dim3 grid((A.n_tiles + T - 1) / T, my, n_samples);                                                             \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true>), grid, dim3(512), ws_bytes, st, A);      \
+        } else {                                                                                                           \
+            A.tiles_per_block = 1;                                                                                         \
+            dim3 grid(A.n_tiles, my, n_samples);                                                                           \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false>), grid, dim3(512), ck_bytes, st, A);     \
+        }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }
-    // tall tiles amortise the in-kernel weight sampling; short ones keep small images from wasting lanes
-    // Pick the largest tile that still gives the chip >= ~3 blocks per CU: big tiles amortise the in-kernel weight
-    // sampling (each sampled weight is reused by every pixel of the tile), small ones keep 256 CUs busy.
-    const auto blocks = [&](int mf, int th) { return (long long)((OW + 31) / 32) * ((OH + th - 1) / th) * ((MOUT + 16 * mf - 1) / (16 * mf)) * n_samples; };
-    const int mf_max = MOUT <= 16 ? 1 : (MOUT <= 32 || MOUT % 64 != 0) ? 2 : 4;
-    const long long want = 768;
+    if (tune_mf() > 0) {       // experiment override: MFVI_TUNE=mf,th,T,blocks
+        const int mf = tune_mf(), th = tune_th();
+        if constexpr (STRIDE == 1) { if (th == 16) { if (mf == 1) GO(1, 16) if (mf == 2) GO(2, 16) } }
+        if (mf == 1) GO(1, 8) if (mf == 2) GO(2, 8) if (mf == 4) GO(4, 8)
+    }
     if constexpr (STRIDE == 1) {
         if (OH >= 16) {
-            if (mf_max == 4 && blocks(4, 16) >= want) GO(4, 16)
             if (mf_max >= 2 && blocks(2, 16) >= want) GO(2, 16)
             if (blocks(1, 16) >= want) GO(1, 16)
         }
@@ -352,7 +446,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
 int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
                          OutDesc out, int n_samples, hipStream_t st)
 {
-    if (g.Cin > MFVI_MAX_C) return -2;
+    if (g.Cin > MFVI_MAX_C || (g.Cin & 3) || (g.w_off & 3)) return -2;      // Philox blocks must tile every weight row
     GView none{};
     if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
     if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
@@ -363,7 +457,7 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, co
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
                               float* dxp, long long dxp_sstride, int n_samples, hipStream_t st)
 {
-    if (g.Cout > MFVI_MAX_C || g.stride != 1) return -2;
+    if (g.Cout > MFVI_MAX_C || g.stride != 1 || (g.Cin & 3) || (g.w_off & 3)) return -2;
     TView none{}; OutDesc od{};
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
     if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);

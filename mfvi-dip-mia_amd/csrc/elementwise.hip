@@ -145,21 +145,35 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
         if (from_a) {
             d = cat_bn ? apply_bwd(cg, gap[pix], ycp[pix]) : gap[pix];
         } else {
-            // adjoint of the bilinear x2 gather: low-res (m, n) collects from hi-res rows 2m-2..2m+2
+            // Adjoint of the bilinear x2 gather (align_corners=False).  Low-res row m feeds hi-res rows 2m-1..2m+2 with
+            // weights .25 .75 .75 .25; at the borders the clamped taps collapse: row 0 gets 1.0 from hi-res row 0 and
+            // the last row 1.0 from the last hi-res row.
             const int m = (int)(pix / dst.W), n = (int)(pix - (long long)m * dst.W);
+            float wy[4], wx[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int oy = 2 * m - 1 + a, ox = 2 * n - 1 + a;
+                float v = (a == 0 || a == 3) ? 0.25f : 0.75f;
+                if (oy < 0 || oy >= H) v = 0.f; else if ((m == 0 && a == 1) || (m == dst.H - 1 && a == 2)) v = 1.f;
+                wy[a] = v;
+                float u = (a == 0 || a == 3) ? 0.25f : 0.75f;
+                if (ox < 0 || ox >= W) u = 0.f; else if ((n == 0 && a == 1) || (n == dst.W - 1 && a == 2)) u = 1.f;
+                wx[a] = u;
+            }
             d = 0.f;
-            for (int oy = max(0, 2 * m - 2); oy <= min(H - 1, 2 * m + 2); ++oy) {
-                int y0, y1; float ly; up_coef(oy, dst.H, y0, y1, ly);
-                const float wy = (y0 == m ? 1.f - ly : 0.f) + (y1 == m ? ly : 0.f);
-                if (wy == 0.f) continue;
-                for (int ox = max(0, 2 * n - 2); ox <= min(W - 1, 2 * n + 2); ++ox) {
-                    int x0, x1; float lx; up_coef(ox, dst.W, x0, x1, lx);
-                    const float wx = (x0 == n ? 1.f - lx : 0.f) + (x1 == n ? lx : 0.f);
-                    if (wx == 0.f) continue;
-                    const long long hp = (long long)oy * W + ox;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (wy[a] == 0.f) continue;
+                const int oy = 2 * m - 1 + a;
+                float rowacc = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (wx[b] == 0.f) continue;
+                    const long long hp = (long long)oy * W + (2 * n - 1 + b);
                     const float g = cat_bn ? apply_bwd(cg, gap[hp], ycp[hp]) : gap[hp];
-                    d = __builtin_fmaf(g, wy * wx, d);
+                    rowacc = __builtin_fmaf(g, wx[b], rowacc);
                 }
+                d = __builtin_fmaf(rowacc, wy[a], d);
             }
         }
         if (dst.stats != nullptr) {
