@@ -2,6 +2,15 @@
 from . import _lib
 from ._build import build
 from .program import Plan, Program, skip_program
-from . import engine
+from . import engine, sharding
+from .nets import Concat, get_net, skip
 
-__all__ = ["build", "Plan", "Program", "skip_program", "_lib", "engine"]
+__all__ = ["build", "Plan", "Program", "skip_program", "_lib", "engine", "sharding", "Concat", "get_net", "skip", "MeanFieldVI", "Conv2dRT",
+           "gaussian_nll"]
+
+
+def __getattr__(name):          # bayes.py needs torch.nn at import: keep `import mfvi_dip_mia_amd` light
+    if name in ("MeanFieldVI", "Conv2dRT", "gaussian_nll"):
+        from . import bayes
+        return getattr(bayes, name)
+    raise AttributeError(name)

@@ -1,0 +1,380 @@
+"""Drop-in for BayTorch's MeanFieldVI wrapper (reference: BayTorch/freq_to_bayes.py:7-89,
+BayTorch/modules/{module,reparam_layers,conv}.py) on the MI355X HIP library.
+
+    net = MeanFieldVI(get_net(...), prior={'mu': 0.0, 'sigma': np.sqrt(temp) * sigma}, replace_layers='all',
+                      device=device, reparam='')
+    out = net(net_input); kl = net.kl(); (nll + temp * kl).backward(); optimizer.step()
+
+Same constructor, same `.forward/.kl()/.parameters()/.modules()/.state_dict()` surface and key names.  Every Conv2d of
+the wrapped skip() net becomes a Conv2dRT parameter holder (W_mu, W_rho, bias_mu, bias_rho); all arithmetic — the
+fused reparameterised convolutions, train-mode BatchNorm, LeakyReLU, bilinear up-sampling, concat, their backward, and
+the KL reduction — runs in libmfvi_hip through one compiled layer program.  torch supplies storage and autograd glue.
+Anything outside the MFVI runners' configuration raises NotImplementedError instead of silently running elsewhere.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .nets import Concat
+from .program import Program
+
+
+class Conv2dRT(nn.Module):
+    """Parameter holder with the attribute surface of BayTorch Conv2dRT/VIModule (modules/conv.py:6-38,
+    modules/module.py:9-85): W_mu, W_rho, bias_mu, bias_rho, prior, kwargs, `_kl`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias, stride, padding, dilation, groups, prior, posteriors, kl_type, owner):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = tuple(kernel_size)
+        self.kwargs = dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
+        self.kl_type = kl_type
+        self.prior_mu, self.prior_sigma = float(prior['mu']), float(prior['sigma']) + 1e-6          # module.py:38
+        self.posterior_mu_initial, self.posterior_rho_initial = posteriors['mu'], posteriors['rho']
+        for name in ('W_mu', 'W_rho', 'bias_mu', 'bias_rho'):          # filled with views of the flat buffer by the owner
+            self.register_parameter(name, None)
+        self._has_bias = bias
+        self.__dict__['_owner'] = owner                                   # not a submodule
+
+    @property
+    def _kl(self):
+        """KL(prior || posterior) of this layer (modules/module.py:64-74), computed by the HIP reduction."""
+        return self.__dict__['_owner']._layer_kl(self)
+
+    def forward(self, x):
+        raise RuntimeError("Conv2dRT layers are executed by the owning MeanFieldVI through the fused HIP layer program")
+
+
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, x, *params):
+        out, token = owner._hip_forward(x)
+        ctx.owner, ctx.token, ctx.x_requires = owner, token, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads, dz = ctx.owner._hip_backward(ctx.token, dout.contiguous(), ctx.x_requires)
+        return (None, dz) + tuple(grads)
+
+
+class _KLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, lo, hi, prior_mu, prior_sigma, *params):
+        ctx.args = (owner, lo, hi, prior_mu, prior_sigma)
+        return owner._hip_kl(lo, hi, prior_mu, prior_sigma)
+
+    @staticmethod
+    def backward(ctx, g):
+        owner, lo, hi, pm, ps = ctx.args
+        return (None, None, None, None, None) + tuple(owner._hip_kl_backward(lo, hi, pm, ps, g))
+
+
+class MeanFieldVI(nn.Module):
+    def __init__(self, net, prior=None, posteriors=None, kl_type='reverse', reparam='local', replace_layers='all',
+                 device=torch.device('cpu'), seed=None, n_samples=1):
+        super().__init__()
+        if reparam == 'local':
+            raise NotImplementedError("local reparameterisation (Conv2dLRT) is not built: every MFVI runner of the reference "
+                                      "passes reparam='' (bayesian_optimization.py:543,1342,2158,3007)")
+        if replace_layers != 'all':
+            raise NotImplementedError("replace_layers=%r: only 'all' (the runners' setting) is built" % (replace_layers,))
+        if kl_type != 'reverse':
+            raise NotImplementedError("kl_type=%r: only 'reverse' (the default, used by all runners) is built" % (kl_type,))
+        prior = {'mu': 0, 'sigma': 0.1} if prior is None else prior                         # modules/module.py:23-30
+        posteriors = {'mu': (0, 0.1), 'rho': (-3., 0.1)} if posteriors is None else posteriors
+        if 'pi' in prior:
+            raise NotImplementedError("scale-mixture priors (MixtureNormal) are not used by the runners and not built")
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise NotImplementedError("this implementation runs on the GPU only (device=%s); there is no CPU path" % device)
+        L.lib()                                              # fail loudly if the HIP library is missing
+        self.device = device
+        self.net = net
+        self.n_samples = int(n_samples)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 63) - 1)
+        self._step = 0
+        self._token = 0
+        self._plans = {}
+        self._sampling = True
+        self._replace(net, prior, posteriors, kl_type)
+        self._flatten(posteriors)
+        self.net = net.to(device) if False else net          # parameters already live on `device` (flat buffer)
+
+    # ------------------------------------------------------------------ construction
+    def _replace(self, module, prior, posteriors, kl_type):
+        """Leaf swap of nn.Conv2d by Conv2dRT, recursing like freq_to_bayes.py:50-89."""
+        for key, m in list(module._modules.items()):
+            if len(m._modules):
+                self._replace(m, prior, posteriors, kl_type)
+            elif isinstance(m, nn.Conv2d):
+                if m.groups != 1 or m.dilation != (1, 1) or m.padding != (0, 0):
+                    raise NotImplementedError("Conv2d with groups/dilation/own padding is outside the skip() family")
+                module._modules[key] = Conv2dRT(m.in_channels, m.out_channels, m.kernel_size, torch.is_tensor(m.bias), m.stride,
+                                                m.padding, m.dilation, m.groups, prior, posteriors, kl_type, self)
+            elif isinstance(m, (nn.Linear, nn.Conv3d)):
+                raise NotImplementedError("Linear / Conv3d Bayesian layers are not part of the inverse-problem nets")
+
+    def _flatten(self, posteriors):
+        """All parameters become views of ONE flat fp32 buffer [MU | RHO | BN] (layout of include/mfvi_hip.h)."""
+        self._vi = [m for m in self.net.modules() if isinstance(m, Conv2dRT)]
+        self._bn = [m for m in self.net.modules() if isinstance(m, nn.BatchNorm2d)]
+        n_vi = 0
+        for m in self._vi:
+            kh, kw = m.kernel_size
+            m._w_off = n_vi; n_vi += m.out_channels * m.in_channels * kh * kw
+            m._b_off = -1
+            if m._has_bias:
+                m._b_off = n_vi; n_vi += m.out_channels
+        n_bn = sum(2 * b.num_features for b in self._bn)
+        self.n_vi, self.n_bn = n_vi, n_bn
+        flat = torch.empty(2 * n_vi + n_bn, dtype=torch.float32, device=self.device)
+        self._flat = flat
+        mu, rho, bn = flat[:n_vi], flat[n_vi:2 * n_vi], flat[2 * n_vi:]
+        mu.normal_(*posteriors['mu']); rho.normal_(*posteriors['rho'])              # modules/module.py:56-62
+        for m in self._vi:
+            kh, kw = m.kernel_size
+            nw = m.out_channels * m.in_channels * kh * kw
+            shape = (m.out_channels, m.in_channels, kh, kw)
+            m.W_mu = nn.Parameter(mu[m._w_off:m._w_off + nw].view(shape)); m.W_rho = nn.Parameter(rho[m._w_off:m._w_off + nw].view(shape))
+            if m._has_bias:
+                m.bias_mu = nn.Parameter(mu[m._b_off:m._b_off + m.out_channels]); m.bias_rho = nn.Parameter(rho[m._b_off:m._b_off + m.out_channels])
+        off = 0
+        for b in self._bn:
+            c = b.num_features
+            if not b.affine:
+                raise NotImplementedError("non-affine BatchNorm")
+            bn[off:off + c] = 1.0; bn[off + c:off + 2 * c] = 0.0
+            b._bn_off = off
+            b.weight = nn.Parameter(bn[off:off + c]); b.bias = nn.Parameter(bn[off + c:off + 2 * c])
+            b.to(self.device)                                  # running stats buffers
+            b.weight.data = bn[off:off + c]; b.bias.data = bn[off + c:off + 2 * c]
+            off += 2 * c
+        self._param_list = []
+        for m in self._vi:
+            self._param_list += [m.W_mu, m.W_rho] + ([m.bias_mu, m.bias_rho] if m._has_bias else [])
+        for b in self._bn:
+            self._param_list += [b.weight, b.bias]
+
+    def _views_intact(self):
+        base = self._flat.data_ptr()
+        m = self._vi[-1]
+        ok = m.W_mu.data_ptr() == base + 4 * m._w_off and m.W_rho.data_ptr() == base + 4 * (self.n_vi + m._w_off)
+        if self._bn:
+            b = self._bn[-1]
+            ok = ok and b.weight.data_ptr() == base + 4 * (2 * self.n_vi + b._bn_off)
+        return ok
+
+    def _reflatten(self):
+        """Re-establish the flat layout if someone replaced parameter storage (.to(), .float(), load with assign=True)."""
+        new = torch.empty_like(self._flat)
+        n_vi = self.n_vi
+        for m in self._vi:
+            nw = m.W_mu.numel()
+            new[m._w_off:m._w_off + nw] = m.W_mu.data.reshape(-1).to(new); new[n_vi + m._w_off:n_vi + m._w_off + nw] = m.W_rho.data.reshape(-1).to(new)
+            if m._has_bias:
+                c = m.out_channels
+                new[m._b_off:m._b_off + c] = m.bias_mu.data.to(new); new[n_vi + m._b_off:n_vi + m._b_off + c] = m.bias_rho.data.to(new)
+        for b in self._bn:
+            c = b.num_features; o = 2 * n_vi + b._bn_off
+            new[o:o + c] = b.weight.data.to(new); new[o + c:o + 2 * c] = b.bias.data.to(new)
+        self._flat = new
+        for m in self._vi:
+            nw = m.W_mu.numel()
+            m.W_mu.data = new[m._w_off:m._w_off + nw].view_as(m.W_mu); m.W_rho.data = new[n_vi + m._w_off:n_vi + m._w_off + nw].view_as(m.W_rho)
+            if m._has_bias:
+                c = m.out_channels
+                m.bias_mu.data = new[m._b_off:m._b_off + c]; m.bias_rho.data = new[n_vi + m._b_off:n_vi + m._b_off + c]
+        for b in self._bn:
+            c = b.num_features; o = 2 * n_vi + b._bn_off
+            b.weight.data = new[o:o + c]; b.bias.data = new[o + c:o + 2 * c]
+
+    # ------------------------------------------------------------------ layer program
+    def _compile(self, cin, H, W):
+        """Symbolic execution of the module tree -> fused-op program (Sequential / Concat / ReflectionPad2d / Conv2dRT /
+        BatchNorm2d / LeakyReLU / Upsample in the order models/skip.py composes them)."""
+        P = Program()
+        vi_iter = iter(self._vi)
+        zin = P.tensor(cin, H, W)
+
+        def fail(what):
+            raise NotImplementedError("module pattern outside the skip() family: " + what)
+
+        def run(m, v):
+            # v = dict(tid, pad, up): pending ReflectionPad2d amount / pending x2 bilinear upsample
+            if isinstance(m, nn.Sequential):
+                for c in m._modules.values():
+                    v = run(c, v)
+                return v
+            if isinstance(m, Concat):
+                kids = list(m._modules.values())
+                if m.dim != 1 or len(kids) != 2:
+                    fail("Concat with dim != 1 or != 2 branches")
+                a, b = run(kids[0], dict(v)), run(kids[1], dict(v))
+                if a['pad'] or a['up'] or b['pad'] or not b['up']:
+                    fail("Concat expects (skip branch, up-sampled deeper branch)")
+                ta, tb = P.tensors[a['tid']], P.tensors[b['tid']]
+                out = P.tensor(ta['C'] + tb['C'], 2 * tb['H'], 2 * tb['W'])
+                P.concat_up(a['tid'], b['tid'], out)
+                return dict(tid=out, pad=0, up=False)
+            if isinstance(m, nn.ReflectionPad2d):
+                p = m.padding
+                if len(set(p)) != 1:
+                    fail("asymmetric ReflectionPad2d")
+                if v['pad'] or v['up']:
+                    fail("ReflectionPad2d after a pending pad/upsample")
+                return dict(v, pad=p[0])
+            if isinstance(m, Conv2dRT):
+                if m is not next(vi_iter):
+                    fail("conv execution order differs from module order")
+                k = m.kernel_size[0]
+                if m.kernel_size[0] != m.kernel_size[1] or v['pad'] != k // 2 or v['up']:
+                    fail("Conv2d must follow ReflectionPad2d(k//2)")
+                stride = m.kwargs['stride'][0] if isinstance(m.kwargs['stride'], (tuple, list)) else m.kwargs['stride']
+                out = P.tensor(m.out_channels, *P.conv_out_hw(v['tid'], k, stride))
+                P.conv(v['tid'], out, k, stride, bias=m._has_bias)
+                lay = P.layers[-1]
+                if lay['w_off'] != m._w_off or lay['b_off'] != m._b_off:
+                    fail("internal: parameter offsets out of sync")
+                return dict(tid=out, pad=0, up=False)
+            if isinstance(m, nn.BatchNorm2d):
+                if v['pad'] or v['up']:
+                    fail("BatchNorm2d after a pending pad/upsample")
+                P.set_bn(v['tid'], act=False, eps=m.eps)
+                if P.bns[-1]['off'] != m._bn_off:
+                    fail("internal: BatchNorm offsets out of sync")
+                return v
+            if isinstance(m, nn.LeakyReLU):
+                t = P.tensors[v['tid']]
+                if not t['has_bn'] or t['has_act'] or v['pad'] or v['up']:
+                    fail("LeakyReLU must directly follow a BatchNorm2d")
+                t['has_act'], t['slope'] = 1, float(m.negative_slope)
+                return v
+            if isinstance(m, nn.Upsample):
+                if m.mode != 'bilinear' or float(m.scale_factor) != 2.0 or m.align_corners:
+                    raise NotImplementedError("Upsample(mode=%r, scale=%r): only bilinear x2 (align_corners=False) is built" % (m.mode, m.scale_factor))
+                if v['pad'] or v['up']:
+                    fail("Upsample after a pending pad/upsample")
+                return dict(v, up=True)
+            fail(type(m).__name__)
+
+        res = run(self.net, dict(tid=zin, pad=0, up=False))
+        if res['pad'] or res['up'] or P.tensors[res['tid']]['has_bn']:
+            fail("the net must end with a convolution")
+        if P.n_vi != self.n_vi or P.n_bn != self.n_bn:
+            fail("internal: parameter count mismatch")
+        return P, zin, res['tid']
+
+    def _plan_for(self, cin, H, W, n):
+        key = (cin, H, W, n)
+        if key not in self._plans:
+            P, zin, zout = self._compile(cin, H, W)
+            self._plans[key] = P.compile(zin, zout, n)
+        return self._plans[key]
+
+    def _blocks(self):
+        if not self._views_intact():
+            self._reflatten()
+        n = self.n_vi
+        return self._flat[:n], self._flat[n:2 * n], self._flat[2 * n:]
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def forward(self, x):
+        if not all(b.training for b in self._bn):
+            raise NotImplementedError("BatchNorm in eval mode (running statistics) is not built: the reference never calls .eval() on "
+                                      "these nets.  For a deterministic pass keep .train() and call set_sampling(False) (w = mu).")
+        return _NetFunction.apply(self, x, *self._param_list)
+
+    def set_sampling(self, enabled=True):
+        """enabled=False reproduces RTLayer's eval branch (w = mu, b = mu_b: reparam_layers.py:33-35) while BatchNorm keeps
+        using batch statistics."""
+        self._sampling = bool(enabled)
+        return self
+
+    def kl(self):
+        """Sum of the layers' KL(prior || posterior) as a tensor of shape [1] (freq_to_bayes.py:43-48)."""
+        m = self._vi[0]
+        vi_params = [p for q in self._vi for p in ([q.W_mu, q.W_rho] + ([q.bias_mu, q.bias_rho] if q._has_bias else []))]
+        return _KLFunction.apply(self, 0, self.n_vi, m.prior_mu, m.prior_sigma, *vi_params)
+
+    def _layer_kl(self, m):
+        hi = (m._b_off + m.out_channels) if m._has_bias else m._w_off + m.W_mu.numel()
+        return self._hip_kl(m._w_off, hi, m.prior_mu, m.prior_sigma)[0]
+
+    # ------------------------------------------------------------------ HIP calls
+    def _hip_forward(self, x):
+        if x.dim() == 4:
+            if x.shape[0] != 1:
+                raise NotImplementedError("batch size %d: the deep-image-prior nets run on one image (batch 1); MC samples are "
+                                          "requested with n_samples" % x.shape[0])
+            x3 = x[0]
+        else:
+            x3 = x
+        x3 = x3.contiguous().float()
+        cin, H, W = x3.shape
+        plan = self._plan_for(cin, H, W, self.n_samples)
+        mu, rho, bn = self._blocks()
+        sample = bool(self.training and self._sampling)
+        step = self._step
+        out = plan.forward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, sample)
+        self._token += 1
+        if sample:
+            self._step += 1                  # fresh eps for every call, like randn_like in VIModule.rsample
+        return out, (self._token, plan, x3, step, sample)
+
+    def _hip_backward(self, token, dout, want_dz):
+        tok, plan, x3, step, sample = token
+        if tok != self._token:
+            raise RuntimeError("backward through a MeanFieldVI forward that is no longer the latest one: the activations live in one "
+                               "workspace per plan.  Draw K Monte-Carlo samples in ONE call (n_samples=K) instead of K calls.")
+        mu, rho, bn = self._blocks()
+        g = torch.zeros(2 * self.n_vi + max(self.n_bn, 1), dtype=torch.float32, device=self.device)
+        n = self.n_vi
+        dz = torch.empty((self.n_samples,) + tuple(x3.shape), device=self.device) if want_dz else None
+        plan.backward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, dout, g[:n], g[n:2 * n], g[2 * n:], sample, dz=dz)
+        grads = []
+        for m in self._vi:
+            nw = m.W_mu.numel()
+            grads += [g[m._w_off:m._w_off + nw].view_as(m.W_mu), g[n + m._w_off:n + m._w_off + nw].view_as(m.W_rho)]
+            if m._has_bias:
+                c = m.out_channels
+                grads += [g[m._b_off:m._b_off + c], g[n + m._b_off:n + m._b_off + c]]
+        for b in self._bn:
+            c = b.num_features; o = 2 * n + b._bn_off
+            grads += [g[o:o + c], g[o + c:o + 2 * c]]
+        if want_dz:
+            dz = dz.sum(0, keepdim=True) if dz.shape[0] > 1 else dz
+        return grads, dz
+
+    def _hip_kl(self, lo, hi, prior_mu, prior_sigma):
+        mu, rho, _ = self._blocks()
+        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        L.check(L.lib().mfvi_kl(L.ptr(mu[lo:hi]), L.ptr(rho[lo:hi]), hi - lo, prior_mu, float(torch.tensor(prior_sigma, dtype=torch.float32)),
+                                L.ptr(acc), L.stream_ptr()))
+        return acc.float()                                   # FloatTensor of shape [1], as the reference returns
+
+    def _hip_kl_backward(self, lo, hi, prior_mu, prior_sigma, gout):
+        mu, rho, _ = self._blocks()
+        n = self.n_vi
+        g = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
+        scale = float(gout.reshape(-1)[0])
+        L.check(L.lib().mfvi_kl_backward(L.ptr(mu[lo:hi]), L.ptr(rho[lo:hi]), hi - lo, prior_mu,
+                                         float(torch.tensor(prior_sigma, dtype=torch.float32)), scale, L.ptr(g[lo:hi]), L.ptr(g[n + lo:n + hi]),
+                                         L.stream_ptr()))
+        grads = []
+        for m in self._vi:
+            nw = m.W_mu.numel()
+            grads += [g[m._w_off:m._w_off + nw].view_as(m.W_mu), g[n + m._w_off:n + m._w_off + nw].view_as(m.W_rho)]
+            if m._has_bias:
+                c = m.out_channels
+                grads += [g[m._b_off:m._b_off + c], g[n + m._b_off:n + m._b_off + c]]
+        return grads
+
+
+def gaussian_nll(mu, neg_logvar, target, reduction='mean'):
+    """utils/bayesian_utils.py:29-32, kept as plain torch for code that calls it on the wrapper's output."""
+    neg_logvar = torch.clamp(neg_logvar, min=-20, max=20)
+    loss = torch.exp(neg_logvar) * torch.pow(target - mu, 2) - neg_logvar
+    return loss.mean() if reduction == 'mean' else loss.sum()

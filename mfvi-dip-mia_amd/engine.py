@@ -15,6 +15,7 @@ import math
 
 from . import _lib as L
 from .program import skip_program
+from .sharding import allreduce_sum_, shard_samples
 
 TASK_DEN, TASK_SR, TASK_CT = "den", "sr", "ct"
 
@@ -27,10 +28,7 @@ class ElboEngine:
         self.task, self.K, self.H, self.W = task, int(K), H, W
         self.rank, self.world = rank, world_size
         self.pg = process_group
-        if self.K % world_size:
-            raise ValueError("K=%d must be divisible by the number of ranks %d" % (K, world_size))
-        self.K_local = self.K // world_size
-        self.k0 = rank * self.K_local
+        self.k0, self.K_local = shard_samples(self.K, rank, world_size)
         self.temp, self.lr, self.seed = float(temp), float(lr), int(seed)
         # prior scale exactly as bayesian_optimization.py:1335-1336 + modules/module.py:38, rounded to fp32
         import numpy as np
@@ -122,7 +120,7 @@ class ElboEngine:
         if self.world > 1:
             # the single exchange of the K-sharded step: grads (+ the NLL scalar) summed over ranks
             self.grads[self.n_params] = self.acc[0].float()
-            self.torch.distributed.all_reduce(self.grads, group=self.pg)
+            allreduce_sum_(self.grads, self.pg)
         if with_kl:
             # KL and its gradient are deterministic: every rank computes them redundantly (no communication)
             L.check(lib.mfvi_kl(L.ptr(self.mu), L.ptr(self.rho), self.n_vi, 0.0, self.prior_sigma, L.ptr(self.acc[1:]), sp))

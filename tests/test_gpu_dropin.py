@@ -1,0 +1,123 @@
+"""GPU tests of the drop-in surface: written the way the reference's runner uses BayTorch
+(bayesian_optimization.py:1327-1372): get_net -> MeanFieldVI -> net(x) -> gaussian_nll + temp*net.kl() -> backward -> AdamW."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mfvi_dip_mia_amd as M_
+    assert torch.cuda.is_available()
+    M_._lib.lib()
+    return M_
+
+
+def _load_flat(net, mu, rho, bnp):
+    n = net.n_vi
+    with torch.no_grad():
+        net._flat[:n].copy_(torch.from_numpy(mu)); net._flat[n:2 * n].copy_(torch.from_numpy(rho)); net._flat[2 * n:].copy_(torch.from_numpy(bnp))
+
+
+def test_state_dict_keys_match_reference(M, golden_dir):
+    g = np.load(os.path.join(golden_dir, "full_den_64_k1.npz"))
+    net = M.get_net(16, 'skip', 'reflection', skip_n33d=[16, 32, 64, 128, 128], skip_n33u=[16, 32, 64, 128, 128], skip_n11=4,
+                    num_scales=5, n_channels=2, upsample_mode='bilinear')
+    net = M.MeanFieldVI(net, prior={'mu': 0.0, 'sigma': 1e-6}, replace_layers='all', device=torch.device('cuda'), reparam='')
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    assert net.n_vi == 1035446 and net.n_bn == 3984
+    assert sum(p.numel() for p in net.parameters()) == 2074876
+    assert all(p.is_leaf and p.is_cuda for p in net.parameters())
+    # initial KL of the den config ~1.29e7 and per-layer _kl adds up
+    net2 = M.MeanFieldVI(M.get_net(16, 'skip', 'reflection', skip_n33d=[16, 32, 64, 128, 128], skip_n33u=[16, 32, 64, 128, 128], skip_n11=4,
+                                   num_scales=5, n_channels=2, upsample_mode='bilinear'),
+                         prior={'mu': 0.0, 'sigma': np.sqrt(5.656911698337764e-07) * 1.4616642493692077e-05}, device=torch.device('cuda'), reparam='')
+    kl = net2.kl()
+    assert kl.shape == (1,) and kl.dtype == torch.float32 and 1.2e7 < float(kl) < 1.4e7
+    per = sum(float(m._kl) for m in net2.modules() if hasattr(m, '_kl'))
+    assert abs(per - float(kl)) < 1e-5 * float(kl)
+
+
+def test_reference_style_training_step(M):
+    kw = dict(H=32, W=32, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+    onet = O.make_net(**kw)
+    seed, temp, sig = 5, 5.656911698337764e-07, 1.4616642493692077e-05
+    mu, rho, bnp = O.init_params(onet, seed)
+    device = torch.device('cuda')
+    net = M.get_net(8, 'skip', 'reflection', skip_n33d=[8, 16, 16], skip_n33u=[8, 16, 16], skip_n11=4, num_scales=3, n_channels=2,
+                    upsample_mode='bilinear')
+    prior = {'mu': 0.0, 'sigma': np.sqrt(temp) * sig}
+    net = M.MeanFieldVI(net, prior=prior, replace_layers='all', device=device, reparam='', seed=seed)
+    _load_flat(net, mu, rho, bnp)
+    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, 8 * 32 * 32)).reshape(1, 8, 32, 32)
+    tgt = O.noisy(O.phantom(32, 32, seed), 0.1, seed)
+    net_input = torch.from_numpy(z).to(device); img = torch.from_numpy(tgt)[None, None].to(device)
+    optimizer = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0)
+    optimizer.zero_grad()
+    out = net(net_input)
+    assert out.shape == (1, 2, 32, 32) and out.requires_grad
+    nll = M.gaussian_nll(out[:, :1], out[:, 1:], img)
+    kl = net.kl()
+    loss = nll + temp * kl
+    loss.backward()
+    ps = float(np.float32(np.sqrt(temp) * sig + 1e-6))
+    r = O.elbo_grad(onet, mu, rho, bnp, z[0], tgt, seed=seed, step=0, K=1, temp=temp, prior_sigma=ps, want_out=True)
+    assert relerr(out.detach().cpu().numpy(), r["out"]) < 1e-4
+    assert abs(float(loss) - r["loss"]) < 1e-4 * abs(r["loss"])
+    n = net.n_vi
+    gmu = np.zeros(n, np.float32); grho = np.zeros(n, np.float32)
+    for m in net._vi:
+        nw = m.W_mu.numel()
+        gmu[m._w_off:m._w_off + nw] = m.W_mu.grad.cpu().numpy().ravel(); grho[m._w_off:m._w_off + nw] = m.W_rho.grad.cpu().numpy().ravel()
+        gmu[m._b_off:m._b_off + m.out_channels] = m.bias_mu.grad.cpu().numpy(); grho[m._b_off:m._b_off + m.out_channels] = m.bias_rho.grad.cpu().numpy()
+    assert relerr(gmu, r["dmu"]) < 3e-4 and relerr(grho, r["drho"]) < 3e-4
+    optimizer.step()
+    p = np.concatenate([mu, rho, bnp]); g = np.concatenate([r["dmu"], r["drho"], r["dbn"]])
+    O.adam(p, g, np.zeros_like(p), np.zeros_like(p), 1e-3, 1)
+    assert net._views_intact()
+    assert np.abs(net._flat.cpu().numpy() - p).max() < 2.1e-3 and np.abs(net._flat.cpu().numpy() - p).mean() < 2e-5
+    # second call draws fresh eps (step 1), like randn_like per call in the reference
+    out2 = net(net_input)
+    ref2, tape = O.net_forward(onet, *[a.cpu().numpy() for a in (net._flat[:n], net._flat[n:2 * n], net._flat[2 * n:])], z[0], seed, 1, 0)
+    tape.free()
+    assert relerr(out2.detach().cpu().numpy()[0], ref2) < 1e-4
+    # RTLayer eval branch: w = mu
+    net.set_sampling(False)
+    out3 = net(net_input)
+    ref3, tape = O.net_forward(onet, *[a.cpu().numpy() for a in (net._flat[:n], net._flat[n:2 * n], net._flat[2 * n:])], z[0], seed, 0, 0, sample_weights=False)
+    tape.free()
+    assert relerr(out3.detach().cpu().numpy()[0], ref3) < 1e-4
+
+
+def test_k_samples_in_one_call_and_errors(M):
+    device = torch.device('cuda')
+    mk = lambda: M.get_net(8, 'skip', 'reflection', skip_n33d=[8, 16], skip_n33u=[8, 16], skip_n11=4, num_scales=2, n_channels=2, upsample_mode='bilinear')
+    net = M.MeanFieldVI(mk(), prior={'mu': 0.0, 'sigma': 0.05}, device=device, reparam='', seed=3, n_samples=4)
+    x = torch.rand(1, 8, 16, 16, device=device) * 0.1
+    out = net(x)
+    assert out.shape == (4, 2, 16, 16)
+    assert float((out[0] - out[1]).abs().max()) > 0            # every sample has its own eps
+    out.mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    o1 = net(x); o2 = net(x)
+    with pytest.raises(RuntimeError, match="no longer the latest"):
+        o1.sum().backward()
+    with pytest.raises(NotImplementedError):
+        M.MeanFieldVI(mk(), device=device)                      # constructor default reparam='local' (LRT) is not built
+    with pytest.raises(NotImplementedError):
+        M.MeanFieldVI(mk(), device=torch.device('cpu'), reparam='')
+    with pytest.raises(NotImplementedError):
+        M.MeanFieldVI(mk(), prior={'mu': 0, 'sigma': 0.1, 'pi': 0.5}, device=device, reparam='')
+    with pytest.raises(NotImplementedError):
+        net.eval(); net(x)

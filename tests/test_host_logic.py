@@ -1,0 +1,124 @@
+"""CPU tests of the host-side mirror of the reference interface: the skip() builder's module names, the layer-program
+compiler's parameter layout, and the K-sharded all-reduce path on two gloo ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_skip_builder_matches_reference_state_dict_keys(golden_dir):
+    """Module names are part of the drop-in contract (checkpoints, notebooks): compare with the key list dumped from the
+    reference's MeanFieldVI(skip(...)) (tests/golden/full_den_64_k1.npz)."""
+    import mfvi_dip_mia_amd as M
+    g = np.load(os.path.join(golden_dir, "full_den_64_k1.npz"))
+    ref = [str(k) for k in g["state_dict_keys"]]
+    net = M.get_net(16, 'skip', 'reflection', skip_n33d=[16, 32, 64, 128, 128], skip_n33u=[16, 32, 64, 128, 128], skip_n11=4,
+                    num_scales=5, n_channels=2, upsample_mode='bilinear')
+    mine = []
+    for k in net.state_dict().keys():
+        if k.endswith(".weight") and "Conv2d" in k:
+            mine += ["net." + k[:-6] + s for s in ("W_mu", "W_rho")]
+        elif k.endswith(".bias") and "Conv2d" in k:
+            mine += ["net." + k[:-4] + s for s in ("bias_mu", "bias_rho")]
+        else:
+            mine.append("net." + k)
+    # the reference registers W_mu, W_rho, bias_mu, bias_rho per layer: same grouping
+    assert mine == ref
+    # layer names in execution order
+    ref_layers = [str(k) for k in g["layer_names"]]
+    my_layers = ["net." + n for n, m in net.named_modules() if isinstance(m, torch.nn.Conv2d)]
+    assert my_layers == ref_layers
+
+
+def test_plain_torch_net_agrees_with_oracle():
+    """The torch module tree itself (not the product path) is a faithful skip(): eval-free forward vs the oracle."""
+    import mfvi_dip_mia_amd as M
+    kw = dict(H=32, W=32, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+    onet = O.make_net(**kw)
+    mu, rho, bnp = O.init_params(onet, 5)
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    net = M.skip(8, 2, num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16], num_channels_skip=[4, 4, 4],
+                 upsample_mode='bilinear', need_sigmoid=False, pad='reflection')
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(convs) == len(conv) and len(bns) == len(bn)
+    with torch.no_grad():
+        for m, r in zip(convs, conv):
+            cin, cout, k, s, wo, bo = [int(v) for v in r]
+            assert (m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0]) == (cin, cout, k, s)
+            m.weight.copy_(torch.from_numpy(mu[wo:wo + cout * cin * k * k].reshape(cout, cin, k, k))); m.bias.copy_(torch.from_numpy(mu[bo:bo + cout]))
+    z = (0.1 * O.uniform_fill(5, 0, 0, 0, 8 * 32 * 32)).reshape(1, 8, 32, 32)
+    out = net(torch.from_numpy(z)).detach().numpy()[0]
+    ref, tape = O.net_forward(onet, mu, rho, bnp, z[0], 5, 0, 0, sample_weights=False)
+    tape.free()
+    assert np.abs(out - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_program_layout_and_unsupported_options():
+    import mfvi_dip_mia_amd as M
+    P, zin, zout, names = M.skip_program(64, 64)
+    conv, bn, n_vi, n_bnp = O.net_table(O.make_net(64, 64))
+    assert (P.n_vi, P.n_bn) == (n_vi, n_bnp) == (1035446, 3984)
+    assert [(l["w_off"], l["b_off"]) for l in P.layers] == [(int(c[4]), int(c[5])) for c in conv]
+    with pytest.raises(NotImplementedError):
+        M.skip(16, 2, need_sigmoid=True, pad='reflection', upsample_mode='bilinear')
+    with pytest.raises(NotImplementedError):
+        M.skip(16, 2, need_sigmoid=False, pad='zero', upsample_mode='bilinear')
+    with pytest.raises(NotImplementedError):
+        M.get_net(16, 'UNet', 'reflection', 'bilinear')
+    assert M.sharding.shard_samples(16, 3, 4) == (12, 4)
+    with pytest.raises(ValueError):
+        M.sharding.shard_samples(10, 0, 4)
+
+
+def _rank_main(rank, world, port, tmp):
+    """One rank of the K-sharded ELBO step on CPU (gloo): the oracle stands in for the HIP kernels; what is under test is
+    the decomposition — global sample keying, ONE all-reduce of the flat buffer, redundant KL, identical Adam on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import mfvi_dip_mia_amd as M
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    O.set_threads(2)
+    kw = dict(H=16, W=16, input_depth=8, n_out=2, nd=(8, 8), nu=(8, 8), ns=(4, 4))
+    net = O.make_net(**kw)
+    K, seed, temp, ps = 4, 11, 5.6e-7, 1e-6
+    mu, rho, bnp = O.init_params(net, seed)
+    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, 8 * 16 * 16)).reshape(8, 16, 16)
+    tgt = O.noisy(O.phantom(16, 16, seed), 0.1, seed)
+    k0, kl_ = M.sharding.shard_samples(K, rank, world)
+    r = O.elbo_grad(net, mu, rho, bnp, z, tgt, seed=seed, step=2, k0=k0, K=kl_, K_total=K, temp=temp, prior_sigma=ps, with_kl=False)
+    flat = torch.from_numpy(np.concatenate([r["dmu"], r["drho"], r["dbn"], np.array([r["nll"]], np.float32)]))
+    M.sharding.allreduce_sum_(flat)
+    n = mu.size
+    kl, dmu, drho = O.kl(mu, rho, ps, scale=temp, want_grad=True)
+    g = flat.numpy().copy(); g[:n] += dmu; g[n:2 * n] += drho
+    p = np.concatenate([mu, rho, bnp]); m = np.zeros_like(p); v = np.zeros_like(p)
+    O.adam(p, g[:p.size], m, v, 1e-3, 1)
+    np.savez(os.path.join(tmp, "rank%d.npz" % rank), g=g, p=p)
+    dist.destroy_process_group()
+
+
+def test_k_sharding_two_gloo_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 500)
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(a["g"], b["g"]) and np.array_equal(a["p"], b["p"])        # every rank holds the same update
+    # and it equals the single-process K=4 result (rank-count invariance of the global sample keying)
+    kw = dict(H=16, W=16, input_depth=8, n_out=2, nd=(8, 8), nu=(8, 8), ns=(4, 4))
+    net = O.make_net(**kw)
+    mu, rho, bnp = O.init_params(net, 11)
+    z = (0.1 * O.uniform_fill(11, 0, 0, 0, 8 * 16 * 16)).reshape(8, 16, 16)
+    tgt = O.noisy(O.phantom(16, 16, 11), 0.1, 11)
+    r = O.elbo_grad(net, mu, rho, bnp, z, tgt, seed=11, step=2, K=4, temp=5.6e-7, prior_sigma=1e-6)
+    full = np.concatenate([r["dmu"], r["drho"], r["dbn"]])
+    assert np.abs(a["g"][:full.size] - full).max() < 1e-5 * np.abs(full).max()
+    assert abs(a["g"][full.size] - r["nll"]) < 1e-5 * abs(r["nll"])
