@@ -10,6 +10,7 @@
 // A tenth MFMA against a constant-one B fragment yields the bias gradient sum_pix dy for free.
 // LDS planes are pitched == 2 (mod 32) floats so the 16 channels x 2 pixels of a half-wave read hit 32 banks.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -39,7 +40,7 @@ template <int KS, int STRIDE>
 __global__ __launch_bounds__(256) void conv_bww_mfma_kernel(TView in, GView gy, ConvGeom g, const float* __restrict__ rho,
                                                             RngKey key, int sample_weights, float* __restrict__ dmu,
                                                             float* __restrict__ drho, int tiles_x, int n_tiles,
-                                                            int tiles_per_block, int ci_tiles)
+                                                            int tiles_per_block, int ci_tiles, int dbg)
 {
     using Cfg = WCfg<KS, STRIDE>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH, KK = Cfg::KK, P = KS / 2, IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_bww_mfma_kernel(TView in, GView gy, 
         }
         __syncthreads();
     }
-    for (int idx = t; idx < 16 * len; idx += 256) {
+    for (int idx = t; idx < 16 * len && !(dbg & 64); idx += 256) {
         const int r = idx / len, rel = idx - r * len, co = co0 + r;
         if (co >= Cout) continue;
         const long long j = ((long long)co * Cin + ci0) * KK + rel;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_bww_mfma_kernel(TView in, GView gy, 
 int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
                                 float* dmu, float* drho, int n_samples, hipStream_t st)
 {
+    static const int dbg = [] { const char* e = getenv("MFVI_DBG"); return e ? atoi(e) : 0; }();
 #define LAUNCH(KS_, S_)                                                                                                        \
     {                                                                                                                          \
         using Cfg = WCfg<KS_, S_>;                                                                                             \
@@ -218,7 +220,7 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
         strips = (n_tiles + tpb - 1) / tpb;                                                                                    \
         dim3 grid(strips, co_tiles * ci_tiles, n_samples);                                                                     \
         hipLaunchKernelGGL((conv_bww_mfma_kernel<KS_, S_>), grid, dim3(256), 0, st, in, gy, g, rho, key, sample_weights, dmu,   \
-                           drho, tiles_x, n_tiles, tpb, ci_tiles);                                                             \
+                           drho, tiles_x, n_tiles, tpb, ci_tiles, dbg);                                                             \
         return (int)hipGetLastError();                                                                                         \
     }
     if (g.ks == 3 && g.stride == 1) LAUNCH(3, 1)
