@@ -131,6 +131,13 @@ int mfvi_sq_err_sum(const float* a, const float* b, int64_t n, double* sum_out, 
 /* SSIM map mean (11x11 Gaussian sigma 1.5, zero padding) of two [H][W] images; ssim_sum overwritten with the
  * sum of the SSIM map (divide by H*W). */
 int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum, void* stream);
+/* One pass of the runner's per-iteration bookkeeping (bayesian_optimization.py:1374-1396) with no host sync: sample means of
+ * out[:,0] and exp(-out[:,1]), EMA (weight w; first = 1 copies), clipped copies for the metrics, ring-buffer slot writes
+ * (slot pointers may be NULL).  C = 2 (den/SR) or 1 (CT: no aleatoric channel). */
+int mfvi_bookkeep(const float* out, int n, int C, int H, int W, float* ema, float ema_weight, int first, float* out_clip,
+                  float* ale_clip, float* avg_clip, float* ring_epi_slot, float* ring_ale_slot, void* stream);
+/* torch.var(ring, dim=0) (unbiased) / torch.mean(ring, dim=0) over R ring-buffer slots (bayesian_optimization.py:1412-1413) */
+int mfvi_ring_stats(const float* ring, int R, int H, int W, float* var_out, float* mean_out, void* stream);
 /* post-step output handling: mean[n][HW] kept, out[:,1] <- exp(-out[:,1]); ema = ema*w + out*(1-w) (first: copy) */
 int mfvi_post_step(float* out, int n, int C, int H, int W, float* ema, float ema_weight, int first, void* stream);
 

@@ -3,9 +3,10 @@ from . import _lib
 from ._build import build
 from .program import Plan, Program, skip_program
 from . import engine, sharding
+from . import runner
 from .nets import Concat, get_net, skip
 
-__all__ = ["build", "Plan", "Program", "skip_program", "_lib", "engine", "sharding", "Concat", "get_net", "skip", "MeanFieldVI", "Conv2dRT",
+__all__ = ["build", "Plan", "Program", "skip_program", "_lib", "engine", "sharding", "runner", "Concat", "get_net", "skip", "MeanFieldVI", "Conv2dRT",
            "gaussian_nll"]
 
 

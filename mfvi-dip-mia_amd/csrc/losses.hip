@@ -159,6 +159,43 @@ __global__ __launch_bounds__(256) void post_step_kernel(float* __restrict__ out,
     }
 }
 
+// Per-iteration bookkeeping of the runner loop (bayesian_optimization.py:1374-1396), one pass over H*W:
+//   m = mean_k out[k][0];  a = mean_k exp(-out[k][1])          (the K-sample generalisation of `out`; K = 1: the reference)
+//   ema = first ? (m, a) : ema*w + (m, a)*(1-w);  clipped copies for PSNR/SSIM;  ring-buffer slot writes
+__global__ __launch_bounds__(256) void bookkeep_kernel(const float* __restrict__ out, int n, int C, long long HW, float* __restrict__ ema,
+                                                       float w, int first, float* __restrict__ out_clip, float* __restrict__ ale_clip,
+                                                       float* __restrict__ avg_clip, float* __restrict__ ring_epi, float* __restrict__ ring_ale)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+        float m = 0.f, a = 0.f;
+        for (int k = 0; k < n; ++k) {
+            m += out[(long long)k * C * HW + i];
+            if (C > 1) a += expf(-out[(long long)k * C * HW + HW + i]);
+        }
+        m /= (float)n; a /= (float)n;
+        const float e0 = first ? m : ema[i] * w + m * (1.f - w);
+        ema[i] = e0;
+        if (C > 1) ema[HW + i] = first ? a : ema[HW + i] * w + a * (1.f - w);
+        const float mc = fminf(fmaxf(m, 0.f), 1.f), ac = fminf(fmaxf(a, 0.f), 1.f);
+        out_clip[i] = mc; avg_clip[i] = fminf(fmaxf(e0, 0.f), 1.f);
+        if (ring_epi) ring_epi[i] = mc;
+        if (C > 1) { ale_clip[i] = ac; if (ring_ale) ring_ale[i] = ac; }
+    }
+}
+
+// torch.var(ring, dim=0) (unbiased) and torch.mean(ring, dim=0) over the R-slot ring buffers (bayesian_optimization.py:1412-1413)
+__global__ __launch_bounds__(256) void ring_stats_kernel(const float* __restrict__ ring, int R, long long HW, float* __restrict__ var_out,
+                                                         float* __restrict__ mean_out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+        double s = 0, q = 0;
+        for (int r = 0; r < R; ++r) { const double v = ring[(long long)r * HW + i]; s += v; q += v * v; }
+        const double mean = s / R;
+        if (mean_out) mean_out[i] = (float)mean;
+        if (var_out) var_out[i] = R > 1 ? (float)((q - R * mean * mean) / (R - 1)) : 0.f;
+    }
+}
+
 inline int nblocks(long long n, int cap = 2048) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 inline RngKey make_key(uint64_t seed, uint32_t domain, uint32_t stream, uint32_t sample, uint32_t step)
 {
@@ -253,6 +290,24 @@ int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum
     for (int i = 0; i < 11; ++i) { win.g[i] = expf(-(float)((i - 5) * (i - 5)) / (2.f * 1.5f * 1.5f)); s += win.g[i]; }
     for (int i = 0; i < 11; ++i) win.g[i] /= s;
     hipLaunchKernelGGL(ssim_kernel, dim3(nblocks((long long)H * W, 1024)), dim3(256), 0, st, a, b, H, W, win, ssim_sum);
+    return (int)hipGetLastError();
+}
+
+int mfvi_bookkeep(const float* out, int n, int C, int H, int W, float* ema, float ema_weight, int first, float* out_clip, float* ale_clip,
+                  float* avg_clip, float* ring_epi_slot, float* ring_ale_slot, void* stream)
+{
+    if (n < 1 || C < 1 || C > 2 || !out || !ema || !out_clip || !avg_clip || (C > 1 && !ale_clip)) { set_error("bookkeep: bad arguments"); return -1; }
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(bookkeep_kernel, dim3(nblocks(HW)), dim3(256), 0, (hipStream_t)stream, out, n, C, HW, ema, ema_weight, first, out_clip,
+                       ale_clip, avg_clip, ring_epi_slot, ring_ale_slot);
+    return (int)hipGetLastError();
+}
+
+int mfvi_ring_stats(const float* ring, int R, int H, int W, float* var_out, float* mean_out, void* stream)
+{
+    if (R < 1 || !ring) { set_error("ring_stats: bad arguments"); return -1; }
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(ring_stats_kernel, dim3(nblocks(HW)), dim3(256), 0, (hipStream_t)stream, ring, R, HW, var_out, mean_out);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,237 @@
+"""Task runners: the reference's run_{den,sr,ct}_mfvi loops (bayesian_optimization.py:1240-1444, 2048-2263, 442-648)
+on the fused ELBO engine, producing the same artefacts (`save.npz` with the dict-of-'mfvi' object arrays that
+eval_denoising.ipynb / eval_sr.ipynb / eval_ct.ipynb read, `locals.txt`).
+
+MI355X-first differences (none changes a stored number's meaning):
+  * the whole per-iteration bookkeeping (EMA, clip, ring buffers, 2 MSE + 3 PSNR + 3 SSIM) runs in HIP kernels that
+    write into device arrays; the host reads them once at the end instead of ~10 `.item()` syncs per iteration;
+  * K Monte-Carlo samples per iteration (K = 1 reproduces the reference); `out` in the bookkeeping is the sample mean;
+  * images come from the caller (array / .npy / image file); the reference's data/ folder is git-ignored upstream, so a
+    seeded synthetic phantom is available (`img='phantom'`).
+CLI:  python -m mfvi_dip_mia_amd.runner --task denoising --bayes mfvi --config configs/mfvi_den.json [--img phantom --imsize 256 --k 16]
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+
+from . import _lib as L
+from .engine import ElboEngine
+
+MC_ITER = 25            # ring-buffer length (bayesian_optimization.py:1314)
+EXP_WEIGHT = 0.99       # EMA weight (:1292)
+
+
+def phantom(H, W, seed):
+    """Seeded synthetic ground truth in [0,1]: soft ellipses, two hard bars, a faint texture."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    img = np.zeros((H, W))
+    for _ in range(6):
+        cx, cy = rng.uniform(-0.6, 0.6, 2); ax, ay = rng.uniform(0.1, 0.5, 2); th = rng.uniform(0, np.pi); amp = rng.uniform(0.2, 0.6)
+        xr = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); yr = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        img += amp / (1.0 + np.exp(np.minimum(((xr / ax) ** 2 + (yr / ay) ** 2 - 1.0) * 8.0, 60.0)))
+    img[int(0.2 * H):int(0.25 * H), int(0.1 * W):int(0.9 * W)] += 0.3
+    img[int(0.1 * H):int(0.9 * H), int(0.7 * W):int(0.74 * W)] += 0.25
+    img += 0.03 * np.sin(9 * xx) * np.cos(7 * yy)
+    img -= img.min(); img /= img.max()
+    return img.astype(np.float32)
+
+
+def _load_image(img, imsize, seed):
+    if isinstance(img, np.ndarray):
+        a = img.astype(np.float32)
+    elif img == "phantom":
+        a = phantom(imsize[0], imsize[1], seed)
+    elif isinstance(img, str) and img.endswith(".npy"):
+        a = np.load(img).astype(np.float32)
+    elif isinstance(img, str):
+        from PIL import Image
+        a = np.asarray(Image.open(img).convert("L"), np.float32) / 255.0       # utils/common_utils.py:179-191
+    else:
+        raise FileNotFoundError("img=%r: the reference's data/ images are not distributed (git-ignored upstream); pass an array, "
+                                "a path, or img='phantom'" % (img,))
+    a = np.squeeze(a)
+    if a.ndim != 2:
+        raise ValueError("expected one grayscale image, got shape %s" % (a.shape,))
+    h, w = a.shape
+    return np.ascontiguousarray(a[:h - h % 32, :w - w % 32])                     # crop to a multiple of 32 (get_image: d=32)
+
+
+class _Book:
+    """Device-side bookkeeping state of one fit."""
+
+    def __init__(self, eng, num_iter, gt, noisy_or_none):
+        import torch
+        self.t = torch
+        H, W, C = eng.H, eng.W, eng.out.shape[1]
+        dev = "cuda"
+        self.C, self.H, self.W = C, H, W
+        self.ema = torch.zeros((C, H, W), device=dev)
+        self.out_clip = torch.zeros((H, W), device=dev); self.ale_clip = torch.zeros((H, W), device=dev); self.avg_clip = torch.zeros((H, W), device=dev)
+        self.ring_epi = torch.zeros((MC_ITER, H, W), device=dev); self.ring_ale = torch.zeros((MC_ITER, H, W), device=dev)
+        self.metrics = torch.zeros((num_iter, 8), dtype=torch.float64, device=dev)     # mse_noisy, mse_gt, 3 psnr-mse, 3 ssim sums
+        self.gt = torch.from_numpy(gt).to(dev); self.noisy = None if noisy_or_none is None else torch.from_numpy(noisy_or_none).to(dev)
+        self.var = torch.zeros((H, W), device=dev); self.ale_mean = torch.zeros((H, W), device=dev)
+
+    def iteration(self, eng, i, n, lr_view=None):
+        lib, sp, p = L.lib(), L.stream_ptr(), L.ptr
+        slot = i % MC_ITER
+        L.check(lib.mfvi_bookkeep(p(eng.out), n, self.C, self.H, self.W, p(self.ema), EXP_WEIGHT, int(i == 0), p(self.out_clip), p(self.ale_clip),
+                                  p(self.avg_clip), p(self.ring_epi[slot]), p(self.ring_ale[slot]) if self.C > 1 else None, sp))
+        m = self.metrics[i]
+        hw = self.H * self.W
+        ref_noisy = self.noisy if self.noisy is not None else self.gt
+        avg0 = self.ema[0]
+        L.check(lib.mfvi_sq_err_sum(p(avg0), p(ref_noisy), hw, p(m[0:]), sp))           # mse(out_avg[:, :1], noisy)  :1389
+        L.check(lib.mfvi_sq_err_sum(p(avg0), p(self.gt), hw, p(m[1:]), sp))              # mse(out_avg[:, :1], gt)     :1390
+        L.check(lib.mfvi_sq_err_sum(p(ref_noisy), p(self.out_clip), hw, p(m[2:]), sp))   # psnr_corrupted              :1398
+        L.check(lib.mfvi_sq_err_sum(p(self.gt), p(self.out_clip), hw, p(m[3:]), sp))     # psnr_gt
+        L.check(lib.mfvi_sq_err_sum(p(self.gt), p(self.avg_clip), hw, p(m[4:]), sp))     # psnr_gt_sm
+        L.check(lib.mfvi_ssim_sum(p(ref_noisy), p(self.out_clip), self.H, self.W, p(m[5:]), sp))
+        L.check(lib.mfvi_ssim_sum(p(self.gt), p(self.out_clip), self.H, self.W, p(m[6:]), sp))
+        L.check(lib.mfvi_ssim_sum(p(self.gt), p(self.avg_clip), self.H, self.W, p(m[7:]), sp))
+
+    def snapshot(self):
+        lib, sp, p = L.lib(), L.stream_ptr(), L.ptr
+        L.check(lib.mfvi_ring_stats(p(self.ring_epi), MC_ITER, self.H, self.W, p(self.var), None, sp))
+        if self.C > 1:
+            L.check(lib.mfvi_ring_stats(p(self.ring_ale), MC_ITER, self.H, self.W, None, p(self.ale_mean), sp))
+        return self.var.cpu().numpy(), self.ale_mean.cpu().numpy(), self.avg_clip.cpu().numpy()
+
+    def results(self):
+        m = self.metrics.cpu().numpy(); hw = self.H * self.W
+        mse_noisy, mse_gt = m[:, 0] / hw, m[:, 1] / hw
+        with np.errstate(divide="ignore"):
+            psnrs = 10.0 * np.log10(1.0 / (m[:, 2:5] / hw))
+        ssims = m[:, 5:8] / hw
+        return mse_noisy, mse_gt, psnrs, ssims
+
+
+def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, factor=4,
+         theta_step=4.0, verbose=False, net_kwargs=None, **unused):
+    import torch
+    timestamp = str(time.time())
+    run_dir = os.path.join(save_path, timestamp)
+    if save:
+        os.makedirs(run_dir, exist_ok=False)
+        with open(os.path.join(run_dir, "locals.txt"), "w") as f:
+            for key, val in dict(task=task, img=img if not isinstance(img, np.ndarray) else "<array>", imsize=imsize, p_sigma=p_sigma,
+                                 num_iter=num_iter, lr=lr, temp=temp, sigma=sigma, input_depth=input_depth, seed=seed, show_every=show_every,
+                                 K=K, save_path=save_path).items():
+                print(key, "=", val, file=f)
+    img_np = _load_image(img, imsize, seed)
+    H, W = img_np.shape
+    num_iter += 1                                                    # bayesian_optimization.py:1291
+    extra = {}
+    noisy = None
+    if task == "den":
+        rng = np.random.default_rng(seed + 1)
+        noisy = np.clip(img_np + rng.normal(scale=p_sigma, size=img_np.shape), 0, 1).astype(np.float32)      # denoising_utils.py:11
+        target = noisy
+        eng = ElboEngine(H, W, task="den", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=net_kwargs)
+    elif task == "sr":
+        target = np.ascontiguousarray(img_np[::factor, ::factor])    # nearest /factor decimation (:2095-2099)
+        noisy = None
+        eng = ElboEngine(H, W, task="sr", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, sr_factor=factor, net_kwargs=net_kwargs)
+        extra["img_lr"] = target
+    else:
+        theta = np.arange(0, 180.0, theta_step, dtype=np.float32)     # :545
+        eng = ElboEngine(H, W, task="ct", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, theta_deg=theta.tolist(), net_kwargs=net_kwargs)
+        sino = torch.empty((len(theta), W), device="cuda")
+        gt_d = torch.from_numpy(img_np).cuda()
+        L.check(L.lib().mfvi_radon_forward(L.ptr(gt_d), L.ptr(eng.theta), 1, H, W, len(theta), L.ptr(sino), L.stream_ptr()))
+        target = sino
+        extra["img_radon"] = sino.cpu().numpy()[None, None]
+    eng.set_target(torch.from_numpy(target) if isinstance(target, np.ndarray) else target)
+    book = _Book(eng, num_iter, img_np, noisy)
+    n_snap = num_iter // show_every + 1
+    recons = np.zeros((n_snap, 1, H, W)); uncerts_epi = np.zeros((n_snap, 1, H, W)); uncerts_ale = np.zeros((n_snap, 1, H, W))
+    t0 = time.perf_counter()
+    for i in range(num_iter):
+        eng.step()                                                    # one fused ELBO iteration (CT keeps the NaN guard inside step)
+        book.iteration(eng, i, eng.chunk)
+        if i % show_every == 0:
+            var, ale, recon = book.snapshot()
+            uncerts_epi[i // show_every, 0] = var; uncerts_ale[i // show_every, 0] = ale; recons[i // show_every, 0] = recon
+            if verbose:
+                nll, kl, loss = eng.losses()
+                print("iter %6d  loss %.5f  nll %.5f  kl %.4e  (%.1f it/s)" % (i, loss, nll, kl, (i + 1) / (time.perf_counter() - t0)))
+    torch.cuda.synchronize()
+    mse_noisy, mse_gt, psnrs, ssims = book.results()
+    if save:
+        wrap = lambda a: {"mfvi": a}
+        np.savez(os.path.join(run_dir, "save.npz"), img_gt=img_np, img_noisy=noisy if noisy is not None else img_np,
+                 mse_noisy=wrap(mse_noisy), mse_gt=wrap(mse_gt), recons=wrap(recons), uncerts=wrap(uncerts_epi), uncerts_ale=wrap(uncerts_ale),
+                 psnrs=wrap(psnrs), ssims=wrap(ssims), **extra)
+        with open(os.path.join(run_dir, "locals.txt"), "a") as f:
+            print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
+        if plot:
+            try:
+                from PIL import Image
+                Image.fromarray((np.clip(recons[-1, 0], 0, 1) * 255).astype(np.uint8)).save(os.path.join(run_dir, "out_avg.png"))
+            except Exception:
+                pass
+    return dict(psnr=float(psnrs[-1, 2]), run_dir=run_dir if save else None, psnrs=psnrs, ssims=ssims, mse_noisy=mse_noisy, mse_gt=mse_gt,
+                recons=recons, uncerts=uncerts_epi, uncerts_ale=uncerts_ale, seconds=time.perf_counter() - t0, engine=eng)
+
+
+def run_den_mfvi(img="phantom", imsize=(256, 256), p_sigma=0.1, num_iter=5000, lr=3e-4, temp=4e-6, sigma=0.01, input_depth=16, seed=42,
+                 show_every=100, plot=False, save=True, save_path="../logs", K=1, **kw):
+    """bayesian_optimization.py:1240-1444.  Returns the dict of results; ['psnr'] is the reference's return value."""
+    return _run("den", img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, **kw)
+
+
+def run_sr_mfvi(img="phantom", imsize=(512, 512), factor=4, num_iter=5000, lr=3e-4, temp=4e-6, sigma=0.01, input_depth=32, seed=42,
+                show_every=100, plot=False, save=True, save_path="../logs", K=1, **kw):
+    """bayesian_optimization.py:2048-2263 (p_sigma is swallowed by **kwargs there too)."""
+    kw.pop("p_sigma", None)
+    return _run("sr", img, imsize, 0.0, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, factor=factor, **kw)
+
+
+def run_ct_mfvi(img="phantom", imsize=(256, 256), num_iter=5000, lr=3e-4, temp=4e-6, sigma=0.01, input_depth=16, seed=42,
+                show_every=100, plot=False, save=True, save_path="../logs", K=1, **kw):
+    """bayesian_optimization.py:442-648."""
+    kw.pop("p_sigma", None)
+    return _run("ct", img, imsize, 0.0, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, **kw)
+
+
+def load_config(path):
+    """The reference's JSON schema {bo_params:{temp:{candidates}, sigma:{candidates}}, run_params:{...}}
+    (bayesian_optimization.py:3901-3909 reads it through pandas; plain json is equivalent)."""
+    cfg = json.load(open(path))
+    rp = dict(cfg["run_params"])
+    for k in ("bo_results_path", "devices"):                          # eval_result.py:21-22
+        rp.pop(k, None)
+    cands = [(t, s) for t in cfg["bo_params"]["temp"]["candidates"] for s in cfg["bo_params"]["sigma"]["candidates"]]
+    return cands, rp
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="denoising", choices=["denoising", "super-resolution", "ct"])
+    ap.add_argument("--bayes", default="mfvi", choices=["mfvi"])
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--img", default=None); ap.add_argument("--imsize", type=int, default=None)
+    ap.add_argument("--k", type=int, default=1); ap.add_argument("--num-iter", type=int, default=None); ap.add_argument("--save-path", default=None)
+    a = ap.parse_args(argv)
+    cands, rp = load_config(a.config)
+    fn = {"denoising": run_den_mfvi, "super-resolution": run_sr_mfvi, "ct": run_ct_mfvi}[a.task]
+    if a.img is not None:
+        rp["img"] = a.img
+    if a.imsize:
+        rp["imsize"] = (a.imsize, a.imsize)
+    if a.num_iter is not None:
+        rp["num_iter"] = a.num_iter
+    if a.save_path:
+        rp["save_path"] = a.save_path
+    rp["plot"] = False
+    for temp, sigma in cands:
+        r = fn(temp=temp, sigma=sigma, K=a.k, verbose=True, **rp)
+        print("temp %.3e sigma %.3e -> PSNR %.3f dB in %.1f s (%s)" % (temp, sigma, r["psnr"], r["seconds"], r["run_dir"]))
+
+
+if __name__ == "__main__":
+    main()

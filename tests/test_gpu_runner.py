@@ -1,0 +1,88 @@
+"""GPU tests of the fused engine on the three tasks (den / SR / CT) against the oracle, and of the runner's artefacts."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mfvi_dip_mia_amd as M_
+    assert torch.cuda.is_available()
+    M_._lib.lib()
+    return M_
+
+
+SMALL = dict(nd=(8, 16), nu=(8, 16), ns=(4, 4))
+
+
+@pytest.mark.parametrize("task,temp,sigma", [("den", 5.656911698337764e-07, 1.4616642493692077e-05), ("sr", 4.381719802264805e-07, 4.9e-08),
+                                             ("ct", 2.2e-10, 1.7e-7)])
+def test_engine_steps_match_oracle(M, task, temp, sigma):
+    """Three fused ELBO iterations (perturbation, K=2 forwards, loss, backward, KL, Adam) vs the oracle doing the same."""
+    H = W = 32; K, seed, lr = 2, 4, 1e-3
+    n_out = 1 if task == "ct" else 2
+    eng = M.engine.ElboEngine(H, W, task=task, K=K, input_depth=8, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=SMALL)
+    onet = O.make_net(H, W, input_depth=8, n_out=n_out, **SMALL)
+    img = O.phantom(H, W, seed)
+    theta = None
+    if task == "den":
+        tgt = O.noisy(img, 0.1, seed)
+    elif task == "sr":
+        tgt = np.ascontiguousarray(img[::4, ::4])
+    else:
+        theta = np.arange(0, 180., 4., dtype=np.float32); tgt = O.radon_fwd(img, theta)
+    eng.set_target(torch.from_numpy(tgt))
+    n = eng.n_vi
+    p = eng.params.cpu().numpy().copy(); z0 = eng.z0.cpu().numpy().copy()
+    # engine init follows the RNG spec (domain INIT / UNIFORM): the oracle regenerates the same numbers
+    mu0, rho0, bn0 = O.init_params(onet, seed)
+    # (bit-equal eps; the affine map a + b*eps is one fma on the device, two roundings in numpy)
+    assert np.abs(p[:n] - mu0).max() < 1e-7 and np.abs(p[n:2 * n] - rho0).max() < 5e-7 and np.array_equal(p[2 * n:], bn0)
+    assert np.abs(z0.ravel() - 0.1 * O.uniform_fill(seed, 0, 0, 0, z0.size)).max() < 1e-8
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    tid = {"den": 0, "sr": 1, "ct": 2}[task]
+    for it in range(3):
+        eng.step()
+        nll, kl, loss = eng.losses()
+        z = z0 + 0.1 * O.normal_fill(seed, 1, 0, 0, it, z0.size).reshape(z0.shape)
+        r = O.elbo_grad(onet, p[:n], p[n:2 * n], p[2 * n:], z, tgt, task=tid, factor=4, theta_deg=theta, seed=seed, step=it, K=K,
+                        temp=temp, prior_sigma=eng.prior_sigma)
+        assert abs(loss - r["loss"]) < 2e-4 * max(abs(r["loss"]), 1e-3), (task, it, loss, r["loss"])
+        O.adam(p, np.concatenate([r["dmu"], r["drho"], r["dbn"]]), m, v, lr, it + 1)
+        d = np.abs(eng.params.cpu().numpy() - p)
+        assert d.max() < 2.5e-3 * (it + 1) and d.mean() < 5e-5 * (it + 1), (task, it, d.max(), d.mean())
+        p = eng.params.cpu().numpy().copy()       # re-anchor: Adam amplifies rounding noise of near-zero gradients
+
+
+def test_runner_artifacts(M, tmp_path):
+    r = M.runner.run_den_mfvi(img="phantom", imsize=(64, 64), num_iter=24, lr=1e-3, temp=5.656911698337764e-07, sigma=1.4616642493692077e-05,
+                              input_depth=16, seed=1, show_every=5, save=True, save_path=str(tmp_path), K=2)
+    z = np.load(os.path.join(r["run_dir"], "save.npz"), allow_pickle=True)
+    # schema read by eval_denoising.ipynb:79-82 (.flat[0]['mfvi'])
+    for key, shape in [("mse_noisy", (25,)), ("mse_gt", (25,)), ("psnrs", (25, 3)), ("ssims", (25, 3)), ("recons", (6, 1, 64, 64)),
+                       ("uncerts", (6, 1, 64, 64)), ("uncerts_ale", (6, 1, 64, 64))]:
+        assert z[key].flat[0]["mfvi"].shape == shape, key
+    assert z["img_gt"].shape == (64, 64) and z["img_noisy"].shape == (64, 64)
+    assert os.path.exists(os.path.join(r["run_dir"], "locals.txt"))
+    ps, ss = z["psnrs"].flat[0]["mfvi"], z["ssims"].flat[0]["mfvi"]
+    assert np.isfinite(ps).all() and np.isfinite(ss).all()
+    # metrics kernels vs the oracle on the stored snapshot of the smoothed reconstruction (iteration 20 = snapshot 4)
+    rec = z["recons"].flat[0]["mfvi"][4, 0].astype(np.float32)
+    assert abs(O.psnr(z["img_gt"], rec) - ps[20, 2]) < 1e-3
+    assert abs(O.ssim(z["img_gt"], rec) - ss[20, 2]) < 1e-4
+    assert abs(float(np.mean((rec - z["img_gt"]) ** 2)) - 10 ** (-ps[20, 2] / 10)) < 1e-6
+    # the fit moves: PSNR of the smoothed output improves over the first 25 iterations
+    assert ps[-1, 2] > ps[0, 2]
+    r2 = M.runner.run_ct_mfvi(img="phantom", imsize=(32, 32), num_iter=4, lr=1e-3, temp=2.2e-10, sigma=1.7e-7, input_depth=8, seed=1, show_every=2,
+                              save=True, save_path=str(tmp_path), K=1, net_kwargs=SMALL)
+    z2 = np.load(os.path.join(r2["run_dir"], "save.npz"), allow_pickle=True)
+    assert z2["img_radon"].shape == (1, 1, 45, 32) and np.isfinite(z2["psnrs"].flat[0]["mfvi"]).all()
+    r3 = M.runner.run_sr_mfvi(img="phantom", imsize=(64, 64), num_iter=4, lr=1e-3, temp=4.4e-7, sigma=4.9e-8, input_depth=8, seed=2, show_every=2,
+                              save=False, K=2, net_kwargs=SMALL)
+    assert np.isfinite(r3["psnrs"]).all()
