@@ -64,7 +64,9 @@ __global__ __launch_bounds__(512, (MF == 1 ? 4 : 2)) void conv_mfma_kernel(MfmaA
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
     constexpr int WCHUNK = KK * CC * CTP;               // floats of one weight chunk (non-WS double buffer)
-    static_assert(MODE == 0 || STRIDE == 1, "backward-data on the MFMA path is stride 1 only");
+    static_assert(MODE == 0 || STRIDE == 1, "backward-data always stages a stride-1 window");
+    // MODE 1 of a stride-2 layer (g.stride == 2): the transposed convolution is the same full correlation over the ZERO-STUFFED
+    // gradient G[r][c] = dy[r/2][c/2] (r, c even), formed on the fly; 3/4 of the MACs multiply zeros, but on the matrix cores.
 
     // Wave specialisation: waves 0-3 (consumers) only issue MFMAs; waves 4-7 (producers) stream the next activation
     // chunk (global loads -> deferred BN/LeakyReLU or BN-backward -> LDS) and sample the next weight chunk into the
@@ -193,7 +195,11 @@ __global__ __launch_bounds__(512, (MF == 1 ? 4 : 2)) void conv_mfma_kernel(MfmaA
                     gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1);       // tile overhang: masked at the store
                     goff[j] = gy * W + gx;
                 } else {
-                    goff[j] = (gy >= 0 && gy < SH && gx >= 0 && gx < SW) ? gy * SW + gx : -1;   // zero padding
+                    if (g.stride == 2) {
+                        const bool ok = gy >= 0 && gx >= 0 && !((gy | gx) & 1) && (gy >> 1) < SH && (gx >> 1) < SW;
+                        goff[j] = ok ? (gy >> 1) * SW + (gx >> 1) : -1;                           // zero-stuffed source
+                    } else
+                        goff[j] = (gy >= 0 && gy < SH && gx >= 0 && gx < SW) ? gy * SW + gx : -1;   // zero padding
                 }
                 if (loff[j] < 0) goff[j] = -1;
             }
@@ -457,7 +463,7 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, co
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
                               float* dxp, long long dxp_sstride, int n_samples, hipStream_t st)
 {
-    if (g.Cout > MFVI_MAX_C || g.stride != 1 || (g.Cin & 3) || (g.w_off & 3)) return -2;
+    if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks == 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
     TView none{}; OutDesc od{};
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
     if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
