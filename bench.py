@@ -120,7 +120,14 @@ def main():
     (dom_op, dom_pass), dom_ms = max(((k_, v) for k_, v in by.items() if k_[1] in (0, 1, 2) and conv_cost(eng.prog, k_[0], 1)), key=lambda kv: kv[1])
     if args.profile_all and rank == 0:
         tot = sum(by.values())
-        for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:40]:
+        cls = {}
+        for (op, ps_), ms in by.items():
+            c = conv_cost(eng.prog, op, eng.chunk)
+            kind = PASS_NAMES[ps_] + (" " + c["desc"].split(" ")[0] + ("/s2" if c["desc"].endswith("s2") else "") if c else "")
+            cls[kind] = cls.get(kind, 0.0) + ms
+        for kind, ms in sorted(cls.items(), key=lambda kv: -kv[1]):
+            sys.stderr.write("  %-22s %8.3f ms %5.1f%%\n" % (kind, ms, 100 * ms / tot))
+        for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:24]:
             c = conv_cost(eng.prog, op, eng.chunk)
             sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else "concat_up"))
         sys.stderr.write("sum of kernel times in one iteration: %.3f ms\n" % tot)
@@ -163,11 +170,9 @@ def main():
                     avg_launch_ms=avg_ms, launches=len(kms), algorithmic_bytes=cost["bytes"], algorithmic_flops=cost["flops"],
                     hbm_gbs_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9, hbm_frac_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):      # HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
+        if os.path.exists(tfile):      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
             try:
-                tj = json.load(open(tfile))
-                if tj.get("kernel_pass") == PASS_NAMES[dom_pass] and tj.get("op") == dom_op:
-                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(tfile))["entries"].get("%s:%s" % (PASS_NAMES[dom_pass], cost["desc"]))
             except Exception:
                 pass
         total_samples = eng.K_local * world * args.steps
