@@ -92,6 +92,17 @@ int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tens
 int mfvi_plan_profile(mfvi_plan* plan, int mode, int op, int pass);
 int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* ops, int* passes, float* ms);
 
+/* Optional, once per plan: run one forward + backward, then time every valid MFMA tiling (output-channel fragments x tile
+ * rows x tiles per block) of every conv op's forward and backward-data kernel with HIP events on `stream` and keep the
+ * fastest per (op, pass).  Tilings do not change any result (same accumulation order per output element).
+ * out_scratch: 2 * n_samples * numel(output tensor) floats; grad_scratch: 2 * n_vi + n_bn floats.  Synchronises `stream`.
+ * Contents of workspace / scratch are undefined afterwards.  MFVI_AUTOTUNE=0 in the environment makes this a no-op. */
+int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, int n_samples,
+                       void* workspace, float* out_scratch, float* grad_scratch, void* stream);
+/* Tiling in use for conv op `op`: which 0 forward, 1 backward-data; (mf | th << 8 | T << 16), 0 = built-in heuristic. */
+int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which);
+int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
+
 /* ---- losses -------------------------------------------------------------------------------------------- */
 /* gaussian_nll (utils/bayesian_utils.py:29-32) for n samples of out[n][2][H][W] against target[H/f][W/f];
  * f > 1 applies the SR projection out[..., ::f, ::f] first (bayesian_optimization.py:2095-2099,2182-2185).

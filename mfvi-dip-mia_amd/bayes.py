@@ -316,6 +316,8 @@ class MeanFieldVI(nn.Module):
         cin, H, W = x3.shape
         plan = self._plan_for(cin, H, W, self.n_samples)
         mu, rho, bn = self._blocks()
+        if not getattr(plan, "tuned", False):      # first use of this plan: pick the fastest tiling per layer (one-time)
+            plan.autotune(mu, rho, bn, x3, self.n_samples)
         sample = bool(self.training and self._sampling)
         step = self._step
         out = plan.forward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, sample)

@@ -236,6 +236,7 @@ struct ConvGeom {
     int Cin, Cout, H, W, Ho, Wo, ks, stride;
     long long w_off, b_off;    // into mu / rho
     int layer_id;
+    int tune[2];               // MFMA tiling chosen by mfvi_plan_autotune for forward / backward-data (0 = heuristic)
 };
 
 struct OutDesc {               // raw output tensor of a forward op

@@ -58,7 +58,7 @@ struct MfmaArgs {
 };
 
 template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS>
-__global__ __launch_bounds__(512, (MF == 1 ? 4 : 2)) void conv_mfma_kernel(MfmaArgs A)
+__global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1))) void conv_mfma_kernel(MfmaArgs A)
 {
     using Cfg = MCfg<KS, STRIDE, MF, TH>;
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
@@ -378,16 +378,12 @@ __global__ __launch_bounds__(512, (MF == 1 ? 4 : 2)) void conv_mfma_kernel(MfmaA
     }
 }
 
-struct Tune { int mf = 0, th = 0, T = 0, blocks = 512; };
-const Tune& tune()
+// Tiling override: MFVI_TUNE=mf,th,T (experiments) or the per-op choice made by mfvi_plan_autotune (ConvGeom::tune).
+int env_tune()
 {
-    static const Tune t = [] { Tune v; const char* e = getenv("MFVI_TUNE"); if (e) sscanf(e, "%d,%d,%d,%d", &v.mf, &v.th, &v.T, &v.blocks); if (v.blocks < 1) v.blocks = 512; return v; }();
+    static const int t = [] { int mf = 0, th = 0, T = 0; const char* e = getenv("MFVI_TUNE"); if (e) sscanf(e, "%d,%d,%d", &mf, &th, &T); return mf > 0 ? (mf | th << 8 | T << 16) : 0; }();
     return t;
 }
-inline int tune_mf() { return tune().mf; }
-inline int tune_th() { return tune().th; }
-inline int tune_T() { return tune().T; }
-inline int tune_blocks() { return tune().blocks; }
 
 template <int KS, int STRIDE, int MODE>
 int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const float* mu, const float* rho, RngKey key,
@@ -404,10 +400,13 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     // (each sampled weight is reused by every pixel of the tile), small ones keep 256 CUs busy.  When the whole slab of a
     // block fits in LDS and there are tiles to spare, go weight-stationary and give each block several tiles.
     const auto blocks = [&](int mf, int th) { return (long long)((OW + 31) / 32) * ((OH + th - 1) / th) * ((MOUT + 16 * mf - 1) / (16 * mf)) * n_samples; };
-    // fewest padded output channels first (36 -> 3x16, not 2x32), larger fragments on ties
-    const auto padded = [&](int mf) { return ((MOUT + 16 * mf - 1) / (16 * mf)) * mf; };
-    const int mf_max = padded(4) <= padded(2) && padded(4) <= padded(1) ? 4 : (padded(2) <= padded(1) ? 2 : 1);
+    // Output-channel fragments per block: padded fragments cost matrix-core time, every extra channel tile re-reads the
+    // whole activation operand -> minimise frags + tiles/2.
+    const auto cost = [&](int mf) { const int tiles = (MOUT + 16 * mf - 1) / (16 * mf); return 2 * tiles * mf + tiles; };
+    int order[4] = {4, 3, 2, 1};
+    for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && cost(order[j]) < cost(order[j - 1]); --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
     const long long want = 768;
+    int forced_T = 0;
 #define GO(MF_, TH_)                                                                                                       \
     {                                                                                                                      \
         using Cfg = MCfg<KS, STRIDE, MF_, TH_>;                                                                            \
@@ -416,33 +415,36 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
         const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP, ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * Cfg::CTP; \
         const long long nb = (long long)A.n_tiles * my * n_samples;                                                        \
-        int T = (int)(nb / tune_blocks()); T = T < 1 ? 1 : (T > 8 ? 8 : T);                                                \
-        if (tune_T() > 0) T = tune_T();                                                                                    \
+        int T = (int)(nb / 512); T = T < 1 ? 1 : (T > 8 ? 8 : T);                                                          \
+        if (forced_T > 0) T = forced_T;                                                                                    \
         if (T >= 2 && ws_bytes <= 40 * 1024) {                                                                             \
             A.tiles_per_block = T;                                                                                         \
             dim3 grid((A.n_tiles + T - 1) / T, my, n_samples);                                                             \
             hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true>), grid, dim3(512), ws_bytes, st, A);      \
         } else {                                                                                                           \
+            if (forced_T > 1) return -3;                                                                                   \
             A.tiles_per_block = 1;                                                                                         \
             dim3 grid(A.n_tiles, my, n_samples);                                                                           \
             hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false>), grid, dim3(512), ck_bytes, st, A);     \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }
-    if (tune_mf() > 0) {       // experiment override: MFVI_TUNE=mf,th,T,blocks
-        const int mf = tune_mf(), th = tune_th();
-        if constexpr (STRIDE == 1) { if (th == 16) { if (mf == 1) GO(1, 16) if (mf == 2) GO(2, 16) } }
-        if (mf == 1) GO(1, 8) if (mf == 2) GO(2, 8) if (mf == 4) GO(4, 8)
+#define GO_MF(mf_, TH_) { if ((mf_) == 1) GO(1, TH_) if ((mf_) == 2) GO(2, TH_) if ((mf_) == 3) GO(3, TH_) }
+    const int forced = g.tune[MODE] ? g.tune[MODE] : env_tune();
+    if (forced) {              // explicit tiling (mf | th << 8 | T << 16); -3 = not a valid tiling for this shape
+        const int mf = forced & 255, th = (forced >> 8) & 255;
+        forced_T = (forced >> 16) & 255;
+        if (th == 16) { if constexpr (STRIDE == 1) { if (OH >= 16) GO_MF(mf, 16) } return -3; }
+        if (th == 8) { GO_MF(mf, 8) if (mf == 4) GO(4, 8) }
+        return -3;
     }
     if constexpr (STRIDE == 1) {
-        if (OH >= 16) {
-            if (mf_max >= 2 && blocks(2, 16) >= want) GO(2, 16)
-            if (blocks(1, 16) >= want) GO(1, 16)
-        }
+        if (OH >= 16)
+            for (int i = 0; i < 4; ++i) if (order[i] <= 3 && !(MODE == 0 && order[i] == 3) && blocks(order[i], 16) >= want) GO_MF(order[i], 16)
     }
-    if (mf_max == 4 && blocks(4, 8) >= want) GO(4, 8)
-    if (mf_max >= 2 && blocks(2, 8) >= want) GO(2, 8)
+    for (int i = 0; i < 4; ++i) if (blocks(order[i], 8) >= want) { GO_MF(order[i], 8) if (order[i] == 4) GO(4, 8) }
     GO(1, 8)
+#undef GO_MF
 #undef GO
 }
 

@@ -283,7 +283,7 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV) {
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st) : -2;
-            if (rc == -2) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
+            if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
             rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, n_samples, st);
@@ -321,7 +321,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                 const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
                 { ProfScope ps(plan, i, PASS_BWD_DATA, st);
                   rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st) : -2;
-                  if (rc == -2) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
+                  if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
                 const TensorInfo& x = plan->t[o.d.in0];
                 if (!rc && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
                     FoldSrc srcs[2]; int ns = 0;
@@ -402,6 +402,86 @@ int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* o
     plan->recs.clear();
     *n_records = n;      /* may exceed capacity: only the first `capacity` were written */
     return 0;
+}
+
+int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which)
+{
+    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 1 || plan->ops[op].d.type != MFVI_OP_CONV) return -1;
+    return plan->ops[op].g.tune[which];
+}
+
+int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune)
+{
+    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 1 || tune < 0 || plan->ops[op].d.type != MFVI_OP_CONV) {
+        set_error("plan_set_tune: bad arguments"); return -1; }
+    plan->ops[op].g.tune[which] = tune;
+    return 0;
+}
+
+int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, int n_samples,
+                       void* workspace, float* out_scratch, float* grad_scratch, void* stream)
+{
+    if (!check_call(plan, n_samples, workspace)) return -1;
+    if (!mu || !rho || !z || !out_scratch || !grad_scratch || (plan->n_bn > 0 && !bn)) { set_error("autotune: null pointer argument"); return -1; }
+    { const char* e = getenv("MFVI_AUTOTUNE"); if ((e && e[0] == '0') || !use_mfma()) return 0; }
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_out = plan->t[plan->output].numel * n_samples;
+    float* out = out_scratch; float* dout = out_scratch + n_out;
+    float* dmu = grad_scratch; float* drho = dmu + plan->n_vi; float* dbn = drho + plan->n_vi;
+    // every tensor, statistic and gradient the kernels read holds finite data: one real forward + backward
+    int rc = mfvi_forward(plan, mu, rho, bn, z, 1, 0, 0, n_samples, 1, workspace, out, stream);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dout, out, sizeof(float) * n_out, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(grad_scratch, 0, sizeof(float) * (2 * plan->n_vi + plan->n_bn), st);
+    if (e != hipSuccess) { set_error("autotune: %s", hipGetErrorString(e)); return (int)e; }
+    rc = mfvi_backward(plan, mu, rho, bn, z, 1, 0, 0, n_samples, 1, workspace, dout, dmu, drho, dbn, nullptr, stream);
+    if (rc) return rc;
+    Ctx c{*plan, (char*)workspace, bn, z, n_samples};
+    const RngKey key = base_key(1, 0, 0);
+    hipEvent_t ea, eb;
+    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { set_error("autotune: hipEventCreate failed"); return -1; }
+    const int reps = 3;
+    for (size_t i = 0; i < plan->ops.size(); ++i) {
+        OpInfo& o = plan->ops[i];
+        if (o.d.type != MFVI_OP_CONV) continue;
+        const TensorInfo& y = plan->t[o.d.out];
+        OutDesc od; od.data = (o.d.out == plan->output) ? out : c.farena() + y.act_off; od.sstride = y.numel;
+        od.stats = y.d.has_bn ? c.fstats() + y.stats_off : nullptr;
+        const GView gy = c.gview(o.d.out, dout);
+        const int P = o.g.ks / 2;
+        const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
+        for (int which = 0; which < 2; ++which) {
+            if (which == 1 && o.d.in0 == plan->input) continue;
+            auto launch = [&]() {
+                return which == 0 ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, mu, rho, key, 1, od, n_samples, st)
+                                  : launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, 1, c.farena() + o.scratch_off, per, n_samples, st);
+            };
+            int best = 0; float best_ms = 1e30f;
+            for (int th = 8; th <= 16; th += 8)
+                for (int mf = 1; mf <= 4; ++mf)
+                    for (int T = 1; T <= 8; T *= 2) {
+                        o.g.tune[which] = mf | th << 8 | T << 16;
+                        rc = launch();                                   // warm-up; -2/-3: shape or tiling not served
+                        if (rc == -2) { T = 99; mf = 99; th = 99; continue; }
+                        if (rc == -3) continue;
+                        if (rc) { set_error("autotune: op %d launch failed: %s", (int)i, rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad arguments"); goto done; }
+                        (void)hipEventRecord(ea, st);
+                        for (int r = 0; r < reps && !rc; ++r) rc = launch();
+                        (void)hipEventRecord(eb, st);
+                        float ms = 0.f;
+                        e = hipEventSynchronize(eb);
+                        if (e == hipSuccess) e = hipEventElapsedTime(&ms, ea, eb);
+                        if (rc || e != hipSuccess) { set_error("autotune: op %d timing failed: %s", (int)i, hipGetErrorString(rc ? (hipError_t)rc : e)); rc = rc ? rc : (int)e; goto done; }
+                        if (ms < best_ms) { best_ms = ms; best = o.g.tune[which]; }
+                    }
+            o.g.tune[which] = best;
+            rc = 0;
+        }
+    }
+done:
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    if (rc) for (auto& o : plan->ops) { o.g.tune[0] = 0; o.g.tune[1] = 0; }
+    return rc;
 }
 
 const char* mfvi_last_error(void) { return g_err; }

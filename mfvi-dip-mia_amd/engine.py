@@ -22,7 +22,8 @@ TASK_DEN, TASK_SR, TASK_CT = "den", "sr", "ct"
 
 class ElboEngine:
     def __init__(self, H, W, task=TASK_DEN, K=1, input_depth=16, temp=1.0, sigma=0.1, lr=1e-3, seed=1, sr_factor=4,
-                 theta_deg=None, rank=0, world_size=1, process_group=None, samples_per_launch=None, net_kwargs=None):
+                 theta_deg=None, rank=0, world_size=1, process_group=None, samples_per_launch=None, net_kwargs=None,
+                 autotune=True):
         import torch
         self.torch = torch
         self.task, self.K, self.H, self.W = task, int(K), H, W
@@ -62,6 +63,8 @@ class ElboEngine:
         self.t = 0
         self.target = None
         self.init_params()
+        if autotune:      # one-time: pick the fastest kernel tiling per layer on this device (results unchanged)
+            self.plan.autotune(self.mu, self.rho, self.bn, self.z0, self.chunk)
 
     # -------------------------------------------------------------------------------------------
     def init_params(self):

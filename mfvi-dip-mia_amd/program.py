@@ -102,6 +102,23 @@ class Plan:
                                       int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(dout), L.ptr(dmu), L.ptr(drho),
                                       L.ptr(dbn), L.ptr(dz), L.stream_ptr()))
 
+    def autotune(self, mu, rho, bn, z, n_samples=None):
+        """Time the valid MFMA tilings of every conv op on this device and keep the fastest (results unchanged)."""
+        import torch
+        n = n_samples or self.max_samples
+        out_scratch = torch.empty(2 * n * self.out_shape[0] * self.out_shape[1] * self.out_shape[2], dtype=torch.float32, device="cuda")
+        grad_scratch = torch.empty(2 * self.prog.n_vi + self.prog.n_bn, dtype=torch.float32, device="cuda")
+        L.check(L.lib().mfvi_plan_autotune(self.handle, L.ptr(mu), L.ptr(rho), L.ptr(bn), L.ptr(z), n, L.ptr(self.workspace),
+                                           L.ptr(out_scratch), L.ptr(grad_scratch), L.stream_ptr()))
+        self.tuned = True
+
+    def tunes(self):
+        """-> {op index: (forward tiling, backward-data tiling)} as (mf, th, T) triples; None = heuristic."""
+        dec = lambda v: None if v <= 0 else (v & 255, (v >> 8) & 255, (v >> 16) & 255)
+        lib = L.lib()
+        return {i: (dec(lib.mfvi_plan_get_tune(self.handle, i, 0)), dec(lib.mfvi_plan_get_tune(self.handle, i, 1)))
+                for i, o in enumerate(self.prog.ops) if o["type"] == L.OP_CONV}
+
     def profile(self, mode, op=-1, pass_=-1):
         L.check(L.lib().mfvi_plan_profile(self.handle, mode, op, pass_))
 
