@@ -65,6 +65,89 @@ __global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrc s0, FoldSrc s1
     }
 }
 
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 4 floats at dword alignment (padded rows)
+typedef float f2a __attribute__((ext_vector_type(2)));
+
+constexpr int V_GROUPS = 4;     // float4 groups per thread in the vector kernels (4096 pixels per block)
+
+// One row `prow` of a padded gradient plane folded horizontally onto pixels q..q+3 of the unpadded row (q % 4 == 0).
+__device__ __forceinline__ float4 fold_row4(const float* __restrict__ base, int prow, int q, int W, int Wp, int pad)
+{
+    const float* __restrict__ p = base + (long long)prow * Wp + q + pad;
+    const f4u v = *reinterpret_cast<const f4u*>(p);
+    float4 r = make_float4(v.x, v.y, v.z, v.w);
+    if (pad) {
+        if (q == 0) r.y += base[(long long)prow * Wp];                     // pixel 1 <- padded column 0
+        if (q + 4 == W) r.z += base[(long long)prow * Wp + W + 1];         // pixel W-2 <- padded column W+1
+    }
+    return r;
+}
+
+// finalize_dx for W % 4 == 0: float4 per lane, 4 groups per thread, loads issued before use.
+__global__ __launch_bounds__(256) void finalize_dx_vec_kernel(FoldSrc s0, FoldSrc s1, int n_src, TView x,
+                                                              float* __restrict__ ga, long long ga_sstride,
+                                                              double* __restrict__ bsums)
+{
+    __shared__ ChanFwd s_ch;
+    __shared__ double s_red[8];
+    const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
+    const int H = x.H, W = x.W, W4 = W >> 2;
+    const long long HW = (long long)H * W;
+    const int n_groups = H * W4;
+    if (t == 0) s_ch = chan_fwd(x, k, c);
+    const bool has_bn = x.stats != nullptr;
+    const float* __restrict__ yx = x.data + (long long)k * x.sstride + (long long)c * HW;
+    float* __restrict__ gout = ga + (long long)k * ga_sstride + (long long)c * HW;
+    float4 d[V_GROUPS], yv[V_GROUPS];
+#pragma unroll
+    for (int it = 0; it < V_GROUPS; ++it) {
+        const int gi = (blockIdx.x * V_GROUPS + it) * 256 + t;
+        d[it] = make_float4(0.f, 0.f, 0.f, 0.f); yv[it] = d[it];
+        if (gi >= n_groups) continue;
+        const int r = gi / W4, q = (gi - r * W4) * 4;
+        for (int s = 0; s < n_src; ++s) {
+            const FoldSrc src = s == 0 ? s0 : s1;
+            const int p = src.pad, Hp = H + 2 * p, Wp = W + 2 * p;
+            const float* __restrict__ base = src.d + (long long)k * src.sstride + (long long)c * Hp * Wp;
+            float4 v = fold_row4(base, r + p, q, W, Wp, p);
+            if (p) {
+                if (r == 1) { const float4 u = fold_row4(base, 0, q, W, Wp, p); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                if (r == H - 2) { const float4 u = fold_row4(base, H + 1, q, W, Wp, p); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            }
+            d[it].x += v.x; d[it].y += v.y; d[it].z += v.z; d[it].w += v.w;
+        }
+        if (has_bn) yv[it] = *reinterpret_cast<const float4*>(yx + (long long)gi * 4);
+    }
+    __syncthreads();
+    const ChanFwd ch = s_ch;
+    double sg = 0.0, sgx = 0.0;
+#pragma unroll
+    for (int it = 0; it < V_GROUPS; ++it) {
+        const int gi = (blockIdx.x * V_GROUPS + it) * 256 + t;
+        if (gi >= n_groups) continue;
+        float dd[4] = {d[it].x, d[it].y, d[it].z, d[it].w};
+        if (has_bn) {
+            const float yy[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = __builtin_fmaf(yy[j] - ch.mean, ch.scale, ch.beta);
+                if (x.act && !(v > 0.f)) dd[j] *= x.slope;
+                sg += (double)dd[j]; sgx += (double)dd[j] * (double)((yy[j] - ch.mean) * ch.rstd);
+            }
+        }
+        *reinterpret_cast<float4*>(gout + (long long)gi * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    }
+    if (has_bn) {
+        const double a = block_sum_d(sg, s_red);
+        const double b = block_sum_d(sgx, s_red);
+        if (t == 0) {
+            double* o = bsums + ((long long)k * x.C + c) * 2;
+            atomicAdd(o, a); atomicAdd(o + 1, b);
+        }
+    }
+}
+
 // bilinear x2, align_corners=False: src = (dst+0.5)/2-0.5 clamped at 0, i1 = min(i0+1, n-1)
 __device__ __forceinline__ void up_coef(int d, int n, int& i0, int& i1, float& l1)
 {
@@ -110,16 +193,88 @@ __global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, 
     }
 }
 
+
+// concat_up forward for W % 4 == 0: every lane writes 4 consecutive pixels of one row.  The upsampled part reads the four
+// low-res columns q/2-1 .. q/2+2 (clamped) of two low-res rows and blends with the same arithmetic as the scalar kernel.
+__global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has_a, TView b, OutDesc out, int H, int W)
+{
+    __shared__ ChanFwd s_ch;
+    __shared__ double s_red[8];
+    const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
+    const int Ca = has_a ? a.C : 0, Ct = Ca + b.C;
+    const long long HW = (long long)H * W;
+    const int W4 = W >> 2, n_groups = H * W4;
+    const bool from_a = c < Ca;
+    if (t == 0) s_ch = from_a ? chan_fwd(a, k, c) : chan_fwd(b, k, c - Ca);
+    __syncthreads();
+    const ChanFwd ch = s_ch;
+    float* __restrict__ o = out.data + (long long)k * out.sstride + (long long)c * HW;
+    double sum = 0.0, sq = 0.0;
+#pragma unroll
+    for (int it = 0; it < V_GROUPS; ++it) {
+        const int gi = (blockIdx.x * V_GROUPS + it) * 256 + t;
+        if (gi >= n_groups) continue;
+        float v[4];
+        if (from_a) {
+            const float4 y = *reinterpret_cast<const float4*>(a.data + (long long)k * a.sstride + (long long)c * HW + (long long)gi * 4);
+            v[0] = apply_fwd(ch, y.x, a.act, a.slope); v[1] = apply_fwd(ch, y.y, a.act, a.slope);
+            v[2] = apply_fwd(ch, y.z, a.act, a.slope); v[3] = apply_fwd(ch, y.w, a.act, a.slope);
+        } else {
+            const int r = gi / W4, q = (gi - r * W4) * 4;
+            int y0, y1; float ly;
+            up_coef(r, b.H, y0, y1, ly);
+            const float* __restrict__ p = b.data + (long long)k * b.sstride + (long long)(c - Ca) * b.H * b.W;
+            const int xb = (q >> 1) - 1;
+            float lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xc = min(max(xb + j, 0), b.W - 1);
+                lo[j] = apply_fwd(ch, p[y0 * b.W + xc], b.act, b.slope);
+                hi[j] = apply_fwd(ch, p[y1 * b.W + xc], b.act, b.slope);
+            }
+            // output column q+j blends low-res columns (x0, x1) with weight lx: interior pattern (0,1,.75) (1,2,.25) (1,2,.75) (2,3,.25);
+            // at q == 0 the clamped source of column 0 is (1,2) with lx = 0 (up_coef) so the value is exact
+            const bool left = q == 0;
+            const int i0[4] = {0, 1, 1, 2};
+            const float lxs[4] = {left ? 0.f : 0.75f, 0.25f, 0.75f, 0.25f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ia = (j == 0 && left) ? 1 : i0[j];
+                const float lx = lxs[j];
+                const float v00 = lo[ia], v01 = lo[ia + 1], v10 = hi[ia], v11 = hi[ia + 1];
+                v[j] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            }
+        }
+        *reinterpret_cast<float4*>(o + (long long)gi * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sum += (double)v[j]; sq += (double)v[j] * (double)v[j]; }
+    }
+    if (out.stats != nullptr) {
+        const double sa = block_sum_d(sum, s_red);
+        const double sb = block_sum_d(sq, s_red);
+        if (t == 0) { double* st = out.stats + ((long long)k * Ct + c) * 2; atomicAdd(st, sa); atomicAdd(st + 1, sb); }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// grid: x = pixel blocks of the DESTINATION tensor (A: H x W, B: H/2 x W/2), y = channel of the concat, z = sample
+// concat_up backward, LDS-tiled.  A block owns one (sample, concat channel) and a tile of CB_TH x CB_TW LOW-res pixels
+// (= 2*CB_TH x 2*CB_TW hi-res pixels of the concat gradient):
+//   channels of A  : elementwise over the hi-res tile (BN-backward of the concat BN on load, LeakyReLU'/BN sums of A);
+//   channels of B  : the hi-res window rows 2*m0-1 .. 2*m0+2*CB_TH, cols 2*n0-1 .. 2*n0+2*CB_TW of dy is staged ONCE
+//                    (coalesced float2 loads), split into even/odd column planes so the stride-2 taps of the bilinear
+//                    adjoint read LDS conflict-free; each thread then gathers its 4x4 taps from LDS.
+constexpr int CB_TH = 16, CB_TW = 64;
+constexpr int CB_ROWS = 2 * CB_TH + 2, CB_PITCH = CB_TW + 1;      // staged rows; entries per even / odd plane row
+
 __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, int has_a, float* __restrict__ ga_a,
                                                             long long ga_a_sstride, double* __restrict__ bsums_a,
                                                             TView b, float* __restrict__ ga_b, long long ga_b_sstride,
-                                                            double* __restrict__ bsums_b)
+                                                            double* __restrict__ bsums_b, int tiles_x)
 {
     __shared__ ChanFwd s_ch;
     __shared__ ChanBwd s_cg;
     __shared__ double s_red[8];
+    __shared__ float s_e[CB_ROWS][CB_PITCH], s_o[CB_ROWS][CB_PITCH];
     const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
     const int Ca = has_a ? a.C : 0;
     const bool from_a = c < Ca;
@@ -131,60 +286,108 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
     const float* __restrict__ gap = gc.ga + (long long)k * gc.gstride + (long long)c * HW;
     const float* __restrict__ ycp = gc.y + (long long)k * gc.ystride + (long long)c * HW;
     const bool cat_bn = gc.stats != nullptr;
+    const int m0 = (blockIdx.x / tiles_x) * CB_TH, n0 = (blockIdx.x % tiles_x) * CB_TW;      // low-res tile origin
     double sg = 0.0, sgx = 0.0;
     const TView& dst = from_a ? a : b;
     const int cd = from_a ? c : c - Ca;
     const long long HWd = (long long)dst.H * dst.W;
-    if ((long long)blockIdx.x * EW_ITEMS * 256 >= HWd) return;     // grid is sized for A; B has a quarter of the pixels
     const float* __restrict__ yd = dst.data + (long long)k * dst.sstride + (long long)cd * HWd;
     float* __restrict__ go = (from_a ? ga_a + (long long)k * ga_a_sstride : ga_b + (long long)k * ga_b_sstride) + (long long)cd * HWd;
-    for (int it = 0; it < EW_ITEMS; ++it) {
-        const long long pix = ((long long)blockIdx.x * EW_ITEMS + it) * 256 + t;
-        if (pix >= HWd) break;
-        float d;
-        if (from_a) {
-            d = cat_bn ? apply_bwd(cg, gap[pix], ycp[pix]) : gap[pix];
-        } else {
-            // Adjoint of the bilinear x2 gather (align_corners=False).  Low-res row m feeds hi-res rows 2m-1..2m+2 with
-            // weights .25 .75 .75 .25; at the borders the clamped taps collapse: row 0 gets 1.0 from hi-res row 0 and
-            // the last row 1.0 from the last hi-res row.
-            const int m = (int)(pix / dst.W), n = (int)(pix - (long long)m * dst.W);
+    const bool dst_bn = dst.stats != nullptr;
+
+    if (from_a) {
+        // hi-res tile rows 2*m0 .. 2*m0+2*CB_TH-1, cols 2*n0 .. 2*n0+2*CB_TW-1, as float2 (W is even)
+        const int r0 = 2 * m0, q0 = 2 * n0;
+        for (int i = t; i < 2 * CB_TH * CB_TW; i += 256) {
+            const int r = r0 + i / CB_TW, q = q0 + (i % CB_TW) * 2;
+            if (r >= H || q >= W) continue;
+            const long long pix = (long long)r * W + q;
+            const f2a g2 = *reinterpret_cast<const f2a*>(gap + pix);
+            float d[2] = {g2.x, g2.y};
+            if (cat_bn) { const f2a y2 = *reinterpret_cast<const f2a*>(ycp + pix); d[0] = apply_bwd(cg, g2.x, y2.x); d[1] = apply_bwd(cg, g2.y, y2.y); }
+            if (dst_bn) {
+                const f2a yv2 = *reinterpret_cast<const f2a*>(yd + pix);
+                const float yy[2] = {yv2.x, yv2.y};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = __builtin_fmaf(yy[j] - ch.mean, ch.scale, ch.beta);
+                    if (dst.act && !(v > 0.f)) d[j] *= dst.slope;
+                    sg += (double)d[j]; sgx += (double)d[j] * (double)((yy[j] - ch.mean) * ch.rstd);
+                }
+            }
+            f2a o2; o2.x = d[0]; o2.y = d[1];
+            *reinterpret_cast<f2a*>(go + pix) = o2;
+        }
+    } else {
+        // ---- stage dy of the hi-res window: local row lr <-> hi-res row 2*m0-1+lr, local col lc <-> hi-res col 2*n0-1+lc;
+        //      even lc -> s_e[lr][lc/2], odd lc -> s_o[lr][lc/2].  Slot 0: lc 0; slots 1..CB_TW: lc (2s-1, 2s); slot CB_TW+1: lc 2*CB_TW+1.
+        const int gr0 = 2 * m0 - 1, gc0 = 2 * n0 - 1;
+        constexpr int SLOTS = CB_TW + 2;
+        for (int i = t; i < CB_ROWS * SLOTS; i += 256) {
+            const int lr = i / SLOTS, sl = i - lr * SLOTS;
+            const int gr = gr0 + lr;
+            const bool rok = gr >= 0 && gr < H;
+            if (sl == 0 || sl == SLOTS - 1) {
+                const int lc = sl == 0 ? 0 : 2 * CB_TW + 1, gq = gc0 + lc;
+                float d = 0.f;
+                if (rok && gq >= 0 && gq < W) {
+                    const long long pix = (long long)gr * W + gq;
+                    d = cat_bn ? apply_bwd(cg, gap[pix], ycp[pix]) : gap[pix];
+                }
+                if (sl == 0) s_e[lr][0] = d; else s_o[lr][CB_TW] = d;
+            } else {
+                const int gq = gc0 + 2 * sl - 1;                   // even hi-res column: float2-aligned
+                float d0 = 0.f, d1 = 0.f;
+                if (rok && gq < W) {
+                    const long long pix = (long long)gr * W + gq;
+                    const f2a g2 = *reinterpret_cast<const f2a*>(gap + pix);
+                    d0 = g2.x; d1 = g2.y;
+                    if (cat_bn) { const f2a y2 = *reinterpret_cast<const f2a*>(ycp + pix); d0 = apply_bwd(cg, g2.x, y2.x); d1 = apply_bwd(cg, g2.y, y2.y); }
+                }
+                s_o[lr][sl - 1] = d0; s_e[lr][sl] = d1;
+            }
+        }
+        __syncthreads();
+        // ---- adjoint of the bilinear x2 gather (align_corners=False).  Low-res row m feeds hi-res rows 2m-1..2m+2 with weights
+        //      .25 .75 .75 .25; at the borders the clamped taps collapse: row 0 gets 1.0 from hi-res row 0 and the last row 1.0
+        //      from the last hi-res row (columns alike).
+        const int nl = t & 63, n = n0 + nl;
+        for (int ml = t >> 6; ml < CB_TH; ml += 4) {
+            const int m = m0 + ml;
+            if (m >= dst.H || n >= dst.W) continue;
             float wy[4], wx[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int oy = 2 * m - 1 + a, ox = 2 * n - 1 + a;
-                float v = (a == 0 || a == 3) ? 0.25f : 0.75f;
-                if (oy < 0 || oy >= H) v = 0.f; else if ((m == 0 && a == 1) || (m == dst.H - 1 && a == 2)) v = 1.f;
-                wy[a] = v;
-                float u = (a == 0 || a == 3) ? 0.25f : 0.75f;
-                if (ox < 0 || ox >= W) u = 0.f; else if ((n == 0 && a == 1) || (n == dst.W - 1 && a == 2)) u = 1.f;
-                wx[a] = u;
+            for (int q = 0; q < 4; ++q) {
+                const int oy = 2 * m - 1 + q, ox = 2 * n - 1 + q;
+                float v = (q == 0 || q == 3) ? 0.25f : 0.75f;
+                if (oy < 0 || oy >= H) v = 0.f; else if ((m == 0 && q == 1) || (m == dst.H - 1 && q == 2)) v = 1.f;
+                wy[q] = v;
+                float u = (q == 0 || q == 3) ? 0.25f : 0.75f;
+                if (ox < 0 || ox >= W) u = 0.f; else if ((n == 0 && q == 1) || (n == dst.W - 1 && q == 2)) u = 1.f;
+                wx[q] = u;
             }
-            d = 0.f;
+            float d = 0.f;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (wy[a] == 0.f) continue;
-                const int oy = 2 * m - 1 + a;
+            for (int q = 0; q < 4; ++q) {
+                const int lr = 2 * ml + q;
                 float rowacc = 0.f;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (wx[b] == 0.f) continue;
-                    const long long hp = (long long)oy * W + (2 * n - 1 + b);
-                    const float g = cat_bn ? apply_bwd(cg, gap[hp], ycp[hp]) : gap[hp];
-                    rowacc = __builtin_fmaf(g, wx[b], rowacc);
-                }
-                d = __builtin_fmaf(rowacc, wy[a], d);
+                rowacc = __builtin_fmaf(s_e[lr][nl], wx[0], rowacc);
+                rowacc = __builtin_fmaf(s_o[lr][nl], wx[1], rowacc);
+                rowacc = __builtin_fmaf(s_e[lr][nl + 1], wx[2], rowacc);
+                rowacc = __builtin_fmaf(s_o[lr][nl + 1], wx[3], rowacc);
+                d = __builtin_fmaf(rowacc, wy[q], d);
             }
+            const long long pix = (long long)m * dst.W + n;
+            if (dst_bn) {
+                const float yv = yd[pix];
+                const float v = __builtin_fmaf(yv - ch.mean, ch.scale, ch.beta);
+                if (dst.act && !(v > 0.f)) d *= dst.slope;
+                sg += (double)d; sgx += (double)d * (double)((yv - ch.mean) * ch.rstd);
+            }
+            go[pix] = d;
         }
-        if (dst.stats != nullptr) {
-            const float yv = yd[pix];
-            const float v = __builtin_fmaf(yv - ch.mean, ch.scale, ch.beta);
-            if (dst.act && !(v > 0.f)) d *= dst.slope;
-            sg += (double)d; sgx += (double)d * (double)((yv - ch.mean) * ch.rstd);
-        }
-        go[pix] = d;
     }
-    if (dst.stats != nullptr) {
+    if (dst_bn) {
         const double sa = block_sum_d(sg, s_red);
         const double sb = block_sum_d(sgx, s_red);
         if (t == 0) {
@@ -222,8 +425,14 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
         set_error("finalize_dx: reflection padding needs H,W >= 2"); return -1;
     }
     const long long HW = (long long)x.H * x.W;
-    dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), x.C, n_samples);
     FoldSrc s0 = srcs[0], s1 = n_src > 1 ? srcs[1] : srcs[0];
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if ((x.W & 3) == 0 && x.H >= 2 && ((x.sstride | ga_sstride) & 3) == 0 && al16(x.data) && al16(ga)) {
+        dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), x.C, n_samples);
+        hipLaunchKernelGGL(finalize_dx_vec_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
+        return (int)hipGetLastError();
+    }
+    dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), x.C, n_samples);
     hipLaunchKernelGGL(finalize_dx_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
     return (int)hipGetLastError();
 }
@@ -233,8 +442,14 @@ int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int n_samp
     const int H = 2 * b.H, W = 2 * b.W;
     const int Ct = (a ? a->C : 0) + b.C;
     const long long HW = (long long)H * W;
-    dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), Ct, n_samples);
     TView av = a ? *a : b;
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if ((W & 3) == 0 && (out.sstride & 3) == 0 && al16(out.data) && (!a || ((a->sstride & 3) == 0 && al16(a->data)))) {
+        dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), Ct, n_samples);
+        hipLaunchKernelGGL(concat_up_fwd_vec_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W);
+        return (int)hipGetLastError();
+    }
+    dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), Ct, n_samples);
     hipLaunchKernelGGL(concat_up_fwd_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W);
     return (int)hipGetLastError();
 }
@@ -243,11 +458,13 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
                          const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int n_samples, hipStream_t st)
 {
     const int Ct = (a ? a->C : 0) + b.C;
-    const long long HW = (long long)gc.H * gc.W;      // A's size; B blocks beyond its pixels exit immediately
-    dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), Ct, n_samples);
+    if ((gc.W & 1) || ((gc.gstride | gc.ystride) & 1) || (a && ((a->sstride | ga_a_sstride) & 1))) {
+        set_error("concat_up_bwd: odd width or sample stride"); return -1; }
+    const int tiles_x = (b.W + CB_TW - 1) / CB_TW, tiles_y = (b.H + CB_TH - 1) / CB_TH;
+    dim3 grid((unsigned)(tiles_x * tiles_y), Ct, n_samples);
     TView av = a ? *a : b;
     hipLaunchKernelGGL(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
-                       ga_b_sstride, bsums_b);
+                       ga_b_sstride, bsums_b, tiles_x);
     return (int)hipGetLastError();
 }
 
