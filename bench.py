@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 DEN = dict(temp=5.656911698337764e-07, sigma=1.4616642493692077e-05, lr=1e-3, seed=1, p_sigma=0.1, input_depth=16)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector == FP32-input MFMA peak
-PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd"}
+PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd", 5: "grad_finalize"}
 
 
 def conv_cost(prog, op_index, n_samples):
@@ -117,19 +117,19 @@ def main():
     by = {}
     for op, ps_, ms in recs:
         by[(op, ps_)] = by.get((op, ps_), 0.0) + ms
-    (dom_op, dom_pass), dom_ms = max(((k_, v) for k_, v in by.items() if k_[1] in (0, 1, 2) and conv_cost(eng.prog, k_[0], 1)), key=lambda kv: kv[1])
+    (dom_op, dom_pass), dom_ms = max(((k_, v) for k_, v in by.items() if k_[1] in (0, 1, 2) and k_[0] >= 0 and conv_cost(eng.prog, k_[0], 1)), key=lambda kv: kv[1])
     if args.profile_all and rank == 0:
         tot = sum(by.values())
         cls = {}
         for (op, ps_), ms in by.items():
-            c = conv_cost(eng.prog, op, eng.chunk)
+            c = conv_cost(eng.prog, op, eng.chunk) if op >= 0 else None
             kind = PASS_NAMES[ps_] + (" " + c["desc"].split(" ")[0] + ("/s2" if c["desc"].endswith("s2") else "") if c else "")
             cls[kind] = cls.get(kind, 0.0) + ms
         for kind, ms in sorted(cls.items(), key=lambda kv: -kv[1]):
             sys.stderr.write("  %-22s %8.3f ms %5.1f%%\n" % (kind, ms, 100 * ms / tot))
         for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:24]:
-            c = conv_cost(eng.prog, op, eng.chunk)
-            sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else "concat_up"))
+            c = conv_cost(eng.prog, op, eng.chunk) if op >= 0 else None
+            sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else ("all layers" if op < 0 else "concat_up")))
         sys.stderr.write("sum of kernel times in one iteration: %.3f ms\n" % tot)
 
     # forward-only rate (extra information, untimed region)

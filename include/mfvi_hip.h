@@ -87,19 +87,20 @@ int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tens
 
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around the plan's launches.
  * mode 0: off; 1: every kernel; 2: only kernel (op, pass).  pass: 0 forward, 1 backward-weight, 2 backward-data,
- * 3 fold/finalize, 4 concat backward.  mfvi_plan_profile_read synchronises the recorded events, writes up to
+ * 3 fold/finalize, 4 concat backward, 5 gradient finalize (op -1).  mfvi_plan_profile_read synchronises the recorded events, writes up to
  * `capacity` records (op index, pass, milliseconds) and clears the log. */
 int mfvi_plan_profile(mfvi_plan* plan, int mode, int op, int pass);
 int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* ops, int* passes, float* ms);
 
 /* Optional, once per plan: run one forward + backward, then time every valid MFMA tiling (output-channel fragments x tile
- * rows x tiles per block) of every conv op's forward and backward-data kernel with HIP events on `stream` and keep the
+ * rows x tiles per block) of every conv op's forward, backward-data and backward-weight kernel with HIP events on `stream` and keep the
  * fastest per (op, pass).  Tilings do not change any result (same accumulation order per output element).
  * out_scratch: 2 * n_samples * numel(output tensor) floats; grad_scratch: 2 * n_vi + n_bn floats.  Synchronises `stream`.
  * Contents of workspace / scratch are undefined afterwards.  MFVI_AUTOTUNE=0 in the environment makes this a no-op. */
 int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, int n_samples,
                        void* workspace, float* out_scratch, float* grad_scratch, void* stream);
-/* Tiling in use for conv op `op`: which 0 forward, 1 backward-data; (mf | th << 8 | T << 16), 0 = built-in heuristic. */
+/* Tiling in use for conv op `op`: which 0 forward, 1 backward-data (mf | th << 8 | T << 16), 2 backward-weight
+ * (input tiles | waves << 8 | block target/256 << 16); 0 = built-in heuristic. */
 int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which);
 int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
 

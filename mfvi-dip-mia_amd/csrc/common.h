@@ -236,7 +236,7 @@ struct ConvGeom {
     int Cin, Cout, H, W, Ho, Wo, ks, stride;
     long long w_off, b_off;    // into mu / rho
     int layer_id;
-    int tune[2];               // MFMA tiling chosen by mfvi_plan_autotune for forward / backward-data (0 = heuristic)
+    int tune[3];               // MFMA tiling chosen by mfvi_plan_autotune for forward / backward-data / backward-weight (0 = heuristic)
 };
 
 struct OutDesc {               // raw output tensor of a forward op
@@ -257,8 +257,16 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, co
                          OutDesc out, int n_samples, hipStream_t st);
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
                               float* dxp, long long dxp_sstride, int n_samples, hipStream_t st);
-int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
-                                float* dmu, float* drho, int n_samples, hipStream_t st);
+// The MFMA backward-weight kernel writes per-(pixel strip, sample) partial sums of dW (and of the bias gradient) with plain
+// stores: part.base[(strip * n_samples + k) * part.stride + j], j < n_w weights then n_b biases; launch_grad_finalize reduces
+// them, multiplies by eps * sigmoid(rho) per sample and accumulates into dmu / drho — no atomics, deterministic.
+struct BwwPart { float* base; long long stride; int max_strips; };
+int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int n_samples,
+                                hipStream_t st);
+struct GradFinEntry { long long w_off, b_off, part_off, stride; int n_w, n_b, strips, layer_id, first_block, pad; };
+int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
+                         int sample_weights, int n_samples, float* dmu, float* drho, hipStream_t st);
+constexpr int GRAD_FIN_QUADS = 64;      // weight quads per block of the finalize kernel
 struct FoldSrc { const float* d; long long sstride; int pad; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.
 int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,

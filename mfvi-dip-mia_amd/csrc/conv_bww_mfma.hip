@@ -5,8 +5,9 @@
 //   D_tap[m = co][n = ci] += A[m][k] * B_tap[k][n],   k = 4 consecutive output pixels of one row,
 //   A = dy (BN-backward formed on load), B_tap = reflection-padded LeakyReLU(BN(x)) shifted by the tap.
 // A block owns one (16 cout) x (16 cin) weight tile and a strip of pixel tiles; its 4 waves split each tile's rows,
-// accumulate 9 fragments each in registers and are summed through LDS at the end.  Epilogue (as the generic path):
-//   d mu += dW,  d rho += dW * eps * sigmoid(rho)  with eps re-derived from the counter RNG, contiguous atomics.
+// accumulate 9 fragments each in registers and are summed through LDS at the end.  The block's partial dW goes to a
+// per-(strip, sample) slab with plain stores; grad_finalize (losses.hip) reduces the slabs and forms
+//   d mu += dW,  d rho += dW * eps * sigmoid(rho)  with eps re-derived from the counter RNG (no atomics, deterministic).
 // A tenth MFMA against a constant-one B fragment yields the bias gradient sum_pix dy for free.
 // LDS planes are pitched == 2 (mod 32) floats so the 16 channels x 2 pixels of a half-wave read hit 32 banks.
 #include "common.h"
@@ -19,52 +20,60 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int pitch2(int n) { return ((n + 29) / 32) * 32 + 2; }        // smallest p >= n with p % 32 == 2
 static_assert(pitch2(256) == 258 && pitch2(340) == 354 && pitch2(2) == 2 && pitch2(3) == 34, "pitch2");
 
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int NB, int NT>
 struct WCfg {
     static constexpr int TW = 32;
     static constexpr int TH = (STRIDE == 1) ? 8 : 4;
     static constexpr int KK = KS * KS;
+    static constexpr int CIB = 16 * NB;                                   // input channels per block
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
     static constexpr int IN_TW = (TW - 1) * STRIDE + KS;
     static constexpr int GPLANE = pitch2(TH * TW);
     static constexpr int XPLANE = pitch2(IN_TH * IN_TW);
-    static constexpr int ROW = 16 * KK;
-    static constexpr int STAGE = 16 * GPLANE + 16 * XPLANE;
-    static constexpr int EPI = 2 * 16 * ROW + 16;
+    static constexpr int ROW = CIB * KK;
+    static constexpr int STAGE = 16 * GPLANE + CIB * XPLANE;
+    static constexpr int EPI = 16 * ROW + 16;
     static constexpr int LDS_FLOATS = STAGE > EPI ? STAGE : EPI;
-    static constexpr int NG = (16 * TH * TW) / 256;                       // dy elements per thread per tile
-    static constexpr int NX = (16 * IN_TH * IN_TW + 255) / 256;           // x elements per thread per tile
 };
 
-template <int KS, int STRIDE>
-__global__ __launch_bounds__(256) void conv_bww_mfma_kernel(TView in, GView gy, ConvGeom g, const float* __restrict__ rho,
-                                                            RngKey key, int sample_weights, float* __restrict__ dmu,
-                                                            float* __restrict__ drho, int tiles_x, int n_tiles,
-                                                            int tiles_per_block, int ci_tiles, int dbg)
+// NB = 16-channel input tiles per block (the dy tile is staged once for all of them), NT = threads per block.
+// SPEC (NT == 512): waves 4-7 are producers (global loads -> deferred BN/LeakyReLU or BN-backward -> LDS, next tile
+// prefetched into registers while the matrix cores run), waves 0-3 consumers that only read LDS and issue MFMAs.
+template <int KS, int STRIDE, int NB, int NT, bool SPEC>
+__global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, ConvGeom g, float* __restrict__ part,
+                                                           long long part_stride, int tiles_x, int n_tiles,
+                                                           int tiles_per_block, int ci_groups)
 {
-    using Cfg = WCfg<KS, STRIDE>;
+    using Cfg = WCfg<KS, STRIDE, NB, NT>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH, KK = Cfg::KK, P = KS / 2, IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW;
-    constexpr int GPLANE = Cfg::GPLANE, XPLANE = Cfg::XPLANE, ROW = Cfg::ROW, NG = Cfg::NG, NX = Cfg::NX;
+    constexpr int GPLANE = Cfg::GPLANE, XPLANE = Cfg::XPLANE, ROW = Cfg::ROW, CIB = Cfg::CIB;
+    constexpr int NS = SPEC ? NT / 2 : NT;            // staging threads
+    constexpr int NW = (SPEC ? NT / 2 : NT) / 64;     // MFMA waves
+    static_assert(!SPEC || NT == 512, "specialised variant is built for 8 waves");
 
-    __shared__ __align__(16) float lds[Cfg::LDS_FLOATS];
-    __shared__ ChanFwd s_chx[16];
+    extern __shared__ __align__(16) float lds[];       // Cfg::LDS_FLOATS
+    __shared__ ChanFwd s_chx[CIB];
     __shared__ ChanBwd s_chg[16];
     float* s_g = lds;                    // [16][GPLANE]
-    float* s_x = lds + 16 * GPLANE;      // [16][XPLANE]
+    float* s_x = lds + 16 * GPLANE;      // [CIB][XPLANE]
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const bool producer = SPEC && t >= NS;
+    const int ts = SPEC ? (t & (NS - 1)) : t;         // staging slot of this thread
     const int k = blockIdx.z;
-    const int co0 = (blockIdx.y / ci_tiles) * 16, ci0 = (blockIdx.y % ci_tiles) * 16;
+    const int co0 = (blockIdx.y / ci_groups) * 16, ci0 = (blockIdx.y % ci_groups) * CIB;
     const int Cin = g.Cin, Cout = g.Cout, H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
     const bool do_bias = (ci0 == 0) && (g.b_off >= 0);
-    const int cot = min(16, Cout - co0), cit = min(16, Cin - ci0);
+    const int cot = min(16, Cout - co0), cit = min(CIB, Cin - ci0);
 
-    if (t < 16) s_chx[t] = chan_fwd(in, k, min(ci0 + t, Cin - 1));
+    if (t < CIB) s_chx[t] = chan_fwd(in, k, min(ci0 + t, Cin - 1));
     if (t >= 64 && t < 80) s_chg[t - 64] = chan_bwd(gy, k, min(co0 + t - 64, Cout - 1));
 
-    f32x4 acc[KK], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NB][KK], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < KK; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < KK; ++q) acc[b][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float* __restrict__ xin = in.data + (long long)k * in.sstride;
     const float* __restrict__ gap = gy.ga + (long long)k * gy.gstride;
@@ -72,44 +81,46 @@ __global__ __launch_bounds__(256) void conv_bww_mfma_kernel(TView in, GView gy, 
     const int HW = H * W, HWo = Ho * Wo;
 
     // Staging slots are fixed per thread: ONE output pixel of the dy tile for 16/CPP channels, NPOS positions of the
-    // input tile for all 16 channels — so a tile costs a handful of index computations, not one per element.
-    constexpr int PIX = TH * TW, CPP = 256 / PIX, NGC = 16 / CPP;          // CPP channels are staged per pass of 256 threads
-    constexpr int NPOS = (IN_TH * IN_TW + 255) / 256;
-    static_assert(256 % PIX == 0 && 16 % CPP == 0, "tile shape");
-    const int gpix = t % PIX, gsub = t / PIX;
-    float gr[NGC], yr[NGC], xr[NPOS][16];
+    // input tile for all CIB channels — so a tile costs a handful of index computations, not one per element.  The next
+    // tile is prefetched into registers while the matrix cores work on the current one.
+    constexpr int PIX = TH * TW, CPP = NS / PIX, NGC = 16 / CPP;           // CPP channels are staged per pass of NS threads
+    constexpr int NPOS = (IN_TH * IN_TW + NS - 1) / NS;
+    static_assert(NS % PIX == 0 && 16 % CPP == 0, "tile shape");
+    const int gpix = ts % PIX, gsub = ts / PIX;
+    float gr[NGC], yr[NGC], xr[NPOS][CIB];
     int goff = -1, xoff[NPOS];
 
     auto prefetch = [&](int tile) {
         const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
         const int yy = oy0 + gpix / TW, xx = ox0 + (gpix % TW);
         goff = (yy < Ho && xx < Wo) ? yy * Wo + xx : -1;
+        // branch-free: every load uses a valid (clamped) address; invalid pixels / channels are zeroed at the LDS store
+        const int gsafe = max(goff, 0);
 #pragma unroll
         for (int j = 0; j < NGC; ++j) {
-            const int c = j * CPP + gsub;
-            const bool ok = goff >= 0 && c < cot;
-            const int off = (co0 + c) * HWo + goff;
-            gr[j] = ok ? gap[off] : 0.f;
-            yr[j] = (ok && yp) ? yp[off] : 0.f;
+            const int off = (co0 + min(j * CPP + gsub, cot - 1)) * HWo + gsafe;
+            gr[j] = gap[off];
+            yr[j] = yp ? yp[off] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
-            const int p = t + 256 * q;
+            const int p = ts + NS * q;
+            xoff[q] = -1;
+            if ((ts & ~63) + NS * q >= IN_TH * IN_TW) continue;          // no lane of this wave owns a position in slot q
+            int xsafe = 0;
             if (p < IN_TH * IN_TW) {
                 const int iy = p / IN_TW, ix = p - iy * IN_TW;
                 int gyy = reflect_idx(oy0 * STRIDE + iy - P, H), gxx = reflect_idx(ox0 * STRIDE + ix - P, W);
                 gyy = min(max(gyy, 0), H - 1); gxx = min(max(gxx, 0), W - 1);         // overhang meets dy == 0
-                xoff[q] = gyy * W + gxx;
-            } else xoff[q] = -1;
+                xoff[q] = xsafe = gyy * W + gxx;
+            }
+            const float* __restrict__ px = xin + (long long)ci0 * HW + xsafe;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) xr[q][c] = (xoff[q] >= 0 && c < cit) ? xin[(ci0 + c) * HW + xoff[q]] : 0.f;
+            for (int c = 0; c < CIB; ++c) xr[q][c] = px[(long long)min(c, cit - 1) * HW];
         }
     };
 
-    const int tile_begin = blockIdx.x * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
-    if (tile_begin < tile_end) prefetch(tile_begin);
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        __syncthreads();
+    auto stage = [&]() {                 // registers -> LDS with the deferred transforms
 #pragma unroll
         for (int j = 0; j < NGC; ++j) {
             const int c = j * CPP + gsub;
@@ -119,113 +130,214 @@ __global__ __launch_bounds__(256) void conv_bww_mfma_kernel(TView in, GView gy, 
         }
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
-            const int p = t + 256 * q;
+            const int p = ts + NS * q;
             if (p < IN_TH * IN_TW) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) s_x[c * XPLANE + p] = c < cit ? apply_fwd(s_chx[c], xr[q][c], in.act, in.slope) : 0.f;
+                for (int c = 0; c < CIB; ++c) s_x[c * XPLANE + p] = c < cit ? apply_fwd(s_chx[c], xr[q][c], in.act, in.slope) : 0.f;
             }
         }
-        __syncthreads();
-        if (tile + 1 < tile_end) prefetch(tile + 1);
-        // ---- MFMA over this wave's rows: k-steps of 4 consecutive pixels ----
-        for (int row = wv; row < TH; row += 4) {
-#pragma unroll 2
-            for (int c4 = 0; c4 < TW; c4 += 4) {
-                const float a = s_g[l15 * GPLANE + row * TW + c4 + l4];
-                const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * IN_TW + (c4 + l4) * STRIDE;
+    };
+    auto mfma_tile = [&]() {             // k-steps of 4 consecutive pixels of one row, dealt round-robin to the MFMA waves
+        for (int ks = wv; ks < TH * (TW / 4); ks += NW) {
+            const int row = ks / (TW / 4), c4 = (ks % (TW / 4)) * 4;
+            const float a = s_g[l15 * GPLANE + row * TW + c4 + l4];
+            const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * IN_TW + (c4 + l4) * STRIDE;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx)
-                        acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[ky * IN_TW + kx], acc[ky * KS + kx], 0, 0, 0);
-                if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);
+                        acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[b * 16 * XPLANE + ky * IN_TW + kx], acc[b][ky * KS + kx], 0, 0, 0);
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);
+        }
+    };
+
+    const int tile_begin = blockIdx.x * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
+    if constexpr (SPEC) {
+        if (producer) {
+            // Producer wave pw stages input channels [pw*CPW, (pw+1)*CPW) and gradient channels [pw*4, pw*4+4): the channel is
+            // wave-uniform, so its BN constants sit in registers and every element costs fma + select + one LDS store.
+            constexpr int CPW = CIB / 4;                                  // input channels per producer wave
+            constexpr int NPX = (IN_TH * IN_TW + 63) / 64;                // passes of 64 lanes over the input tile
+            constexpr int NPG = PIX / 64;                                 // passes over the output-pixel tile
+            const int pw = wv - NW;
+            float pxr[CPW][NPX], pgr[4][NPG], pyr[4][NPG];
+            int pxo[NPX], pgo[NPG];
+            ChanFwd cx[CPW]; ChanBwd cgk[4];
+            __syncthreads();                                             // (S0) channel tables visible
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) cx[i] = s_chx[pw * CPW + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cgk[i] = s_chg[pw * 4 + i];
+            auto pfetch = [&](int tile) {
+                const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+#pragma unroll
+                for (int j = 0; j < NPG; ++j) {
+                    const int px = lane + 64 * j, yy = oy0 + px / TW, xx = ox0 + (px % TW);
+                    pgo[j] = (yy < Ho && xx < Wo) ? yy * Wo + xx : -1;
+                    const int gsafe = max(pgo[j], 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int off = (co0 + min(pw * 4 + i, cot - 1)) * HWo + gsafe;
+                        pgr[i][j] = gap[off];
+                        pyr[i][j] = yp ? yp[off] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NPX; ++j) {
+                    const int p = lane + 64 * j;
+                    pxo[j] = -1;
+                    int xsafe = 0;
+                    if (p < IN_TH * IN_TW) {
+                        const int iy = p / IN_TW, ix = p - iy * IN_TW;
+                        int gyy = reflect_idx(oy0 * STRIDE + iy - P, H), gxx = reflect_idx(ox0 * STRIDE + ix - P, W);
+                        gyy = min(max(gyy, 0), H - 1); gxx = min(max(gxx, 0), W - 1);         // overhang meets dy == 0
+                        pxo[j] = xsafe = gyy * W + gxx;
+                    }
+#pragma unroll
+                    for (int i = 0; i < CPW; ++i) pxr[i][j] = xin[(long long)(ci0 + min(pw * CPW + i, cit - 1)) * HW + xsafe];
+                }
+            };
+            auto pstage = [&]() {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = pw * 4 + i;
+#pragma unroll
+                    for (int j = 0; j < NPG; ++j) {
+                        float v = 0.f;
+                        if (pgo[j] >= 0 && c < cot) v = yp ? apply_bwd(cgk[i], pgr[i][j], pyr[i][j]) : pgr[i][j];
+                        s_g[c * GPLANE + lane + 64 * j] = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CPW; ++i) {
+                    const int c = pw * CPW + i;
+#pragma unroll
+                    for (int j = 0; j < NPX; ++j) {
+                        const int p = lane + 64 * j;
+                        if (p < IN_TH * IN_TW) s_x[c * XPLANE + p] = c < cit ? apply_fwd(cx[i], pxr[i][j], in.act, in.slope) : 0.f;
+                    }
+                }
+            };
+            if (tile_begin < tile_end) pfetch(tile_begin);
+            for (int tile = tile_begin; tile < tile_end; ++tile) {
+                if (tile > tile_begin) __syncthreads();                  // (B1) consumers are done with the previous tile
+                pstage();
+                __syncthreads();                                         // (B2) tile published
+                if (tile + 1 < tile_end) pfetch(tile + 1);
             }
+        } else {
+            __syncthreads();                                             // (S0)
+            for (int tile = tile_begin; tile < tile_end; ++tile) {
+                if (tile > tile_begin) __syncthreads();                  // (B1)
+                __syncthreads();                                         // (B2)
+                mfma_tile();
+            }
+        }
+    } else {
+        if (tile_begin < tile_end) prefetch(tile_begin);
+        for (int tile = tile_begin; tile < tile_end; ++tile) {
+            __syncthreads();
+            stage();
+            __syncthreads();
+            if (tile + 1 < tile_end) prefetch(tile + 1);
+            mfma_tile();
         }
     }
 
-    // ---- sum the 4 waves through LDS.  D layout: column n (ci) = lane & 15, row m (co) = (lane >> 4) * 4 + reg ----
+    // ---- sum the waves through LDS.  D layout: column n (ci) = lane & 15, row m (co) = (lane >> 4) * 4 + reg ----
     __syncthreads();
     float* s_dw = lds;                  // [16][ROW]   dW tile, element (co, ci*KK + tap)
-    float* s_dr = lds + 16 * ROW;       // [16][ROW]   dW * eps * sigmoid(rho)
-    float* s_db = lds + 2 * 16 * ROW;   // [16]
-    for (int i = t; i < 16 * ROW; i += 256) s_dw[i] = 0.f;
+    float* s_db = lds + 16 * ROW;       // [16]
+    for (int i = t; i < 16 * ROW; i += NT) s_dw[i] = 0.f;
     if (t < 16) s_db[t] = 0.f;
     __syncthreads();
+    if (!producer) {
 #pragma unroll
-    for (int q = 0; q < KK; ++q)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&s_dw[(l4 * 4 + r) * ROW + l15 * KK + q], acc[q][r]);
-    if (do_bias && l15 == 0)
+            for (int q = 0; q < KK; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&s_db[l4 * 4 + r], accb[r]);
+                for (int r = 0; r < 4; ++r) atomicAdd(&s_dw[(l4 * 4 + r) * ROW + (b * 16 + l15) * KK + q], acc[b][q][r]);
+        if (do_bias && l15 == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&s_db[l4 * 4 + r], accb[r]);
+    }
     __syncthreads();
 
+    // ---- this block's partial sums -> its slab (contiguous rows; every (strip, sample) slab is covered exactly once) ----
     const int len = cit * KK;
-    RngKey kw = key; kw.sample += (uint32_t)k; kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * g.layer_id);
-    if (sample_weights) {
-        const int G = (len >> 2) + 2;
-        for (int idx = t; idx < 16 * G; idx += 256) {
-            const int r = idx / G, gi = idx - r * G, co = co0 + r;
-            if (co >= Cout) continue;
-            const long long j0 = ((long long)co * Cin + ci0) * KK;
-            const long long blk = (j0 >> 2) + gi, jb = blk << 2;
-            if (jb >= j0 + len) continue;
-            float z[4]; spec_normal4(kw, (uint32_t)blk, z);
-#pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                const long long j = jb + l;
-                if (j >= j0 && j < j0 + len) {
-                    const int rel = (int)(j - j0);
-                    s_dr[r * ROW + rel] = s_dw[r * ROW + rel] * z[l] * sigmoid_f(rho[g.w_off + j]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    for (int idx = t; idx < 16 * len && !(dbg & 64); idx += 256) {
+    float* __restrict__ o = part + ((long long)blockIdx.x * gridDim.z + k) * part_stride;
+    for (int idx = t; idx < 16 * len; idx += NT) {
         const int r = idx / len, rel = idx - r * len, co = co0 + r;
-        if (co >= Cout) continue;
-        const long long j = ((long long)co * Cin + ci0) * KK + rel;
-        atomicAdd(dmu + g.w_off + j, s_dw[r * ROW + rel]);
-        if (sample_weights) atomicAdd(drho + g.w_off + j, s_dr[r * ROW + rel]);
+        if (co < Cout) o[((long long)co * Cin + ci0) * KK + rel] = s_dw[r * ROW + rel];
     }
-    if (do_bias && t < cot) {
-        const int co = co0 + t;
-        const float bsum = s_db[t];
-        atomicAdd(dmu + g.b_off + co, bsum);
-        if (sample_weights) {
-            RngKey kb = kw; kb.stream += 1u;
-            float z[4]; spec_normal4(kb, (uint32_t)(co >> 2), z);
-            atomicAdd(drho + g.b_off + co, bsum * z[co & 3] * sigmoid_f(rho[g.b_off + co]));
-        }
-    }
+    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = s_db[t];
+}
+
+int env_tune_w()
+{
+    static const int t = [] { int nb = 0, w = 0, tb = 0; const char* e = getenv("MFVI_TUNE_W"); if (e) sscanf(e, "%d,%d,%d", &nb, &w, &tb); return nb > 0 ? (nb | w << 8 | tb << 16) : 0; }();
+    return t;
 }
 
 }  // namespace
 
-int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
-                                float* dmu, float* drho, int n_samples, hipStream_t st)
+// Tiling (ConvGeom::tune[2], MFVI_TUNE_W=nb,w,target/256): nb | w << 8 | (target blocks / 256) << 16 with w = 4 (4 waves),
+// 8 (8 waves) or 9 (8 waves, producer/consumer specialised); 0 = heuristic.
+int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int n_samples,
+                                hipStream_t st)
 {
-    static const int dbg = [] { const char* e = getenv("MFVI_DBG"); return e ? atoi(e) : 0; }();
-#define LAUNCH(KS_, S_)                                                                                                        \
+    if (!part.base || part.max_strips < 1 || (g.Cin & 3) || (g.w_off & 3)) return -2;
+    int cfg = g.tune[2] ? g.tune[2] : env_tune_w();
+    const bool forced = cfg != 0;
+    if (!cfg) {
+        // heuristic: stage dy once for up to 48 input channels when the layer has them; 8 waves when the tile is big
+        const int nb = g.Cin > 32 ? 3 : (g.Cin > 16 ? 2 : 1);
+        cfg = nb | ((nb >= 2 ? 9 : 4) << 8) | ((nb >= 2 ? 1 : 6) << 16);
+    }
+    const int nb = cfg & 255, wfield = (cfg >> 8) & 255, target = ((cfg >> 16) & 255) * 256;
+    const bool spec = wfield == 9;
+    const int nt = spec ? 512 : wfield * 64;
+#define LAUNCH(KS_, S_, NB_, NT_, SP_)                                                                                            \
     {                                                                                                                          \
-        using Cfg = WCfg<KS_, S_>;                                                                                             \
+        using Cfg = WCfg<KS_, S_, NB_, NT_>;                                                                                   \
+        constexpr size_t lds_bytes = sizeof(float) * Cfg::LDS_FLOATS;                                                          \
+        if (lds_bytes > 150 * 1024) return -3;                                                                                 \
         const int tiles_x = (g.Wo + Cfg::TW - 1) / Cfg::TW, tiles_y = (g.Ho + Cfg::TH - 1) / Cfg::TH;                          \
         const int n_tiles = tiles_x * tiles_y;                                                                                 \
-        const int co_tiles = (g.Cout + 15) / 16, ci_tiles = (g.Cin + 15) / 16;                                                 \
-        const long long pairs = (long long)co_tiles * ci_tiles * n_samples;                                                    \
-        int strips = (int)((1536 + pairs - 1) / pairs);                                                                        \
+        const int co_tiles = (g.Cout + 15) / 16, ci_groups = (g.Cin + Cfg::CIB - 1) / Cfg::CIB;                                \
+        if (forced && NB_ > 1 && ci_groups == 1 && 16 * (NB_ - 1) >= g.Cin) return -3;   /* an input tile would be empty */           \
+        const long long pairs = (long long)co_tiles * ci_groups * n_samples;                                                   \
+        int strips = (int)((target + pairs - 1) / pairs);                                                                      \
         strips = strips < 1 ? 1 : (strips > n_tiles ? n_tiles : strips);                                                       \
+        if (strips > part.max_strips) strips = part.max_strips;                                                                \
         const int tpb = (n_tiles + strips - 1) / strips;                                                                       \
         strips = (n_tiles + tpb - 1) / tpb;                                                                                    \
-        dim3 grid(strips, co_tiles * ci_tiles, n_samples);                                                                     \
-        hipLaunchKernelGGL((conv_bww_mfma_kernel<KS_, S_>), grid, dim3(256), 0, st, in, gy, g, rho, key, sample_weights, dmu,   \
-                           drho, tiles_x, n_tiles, tpb, ci_tiles, dbg);                                                             \
+        auto kern = conv_bww_mfma_kernel<KS_, S_, NB_, NT_, SP_>;                                                                  \
+        if (lds_bytes > 64 * 1024) {                                                                                           \
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (attr != hipSuccess) return (int)attr;                                                                          \
+        }                                                                                                                      \
+        dim3 grid(strips, co_tiles * ci_groups, n_samples);                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(NT_), lds_bytes, st, in, gy, g, part.base, part.stride, tiles_x, n_tiles, tpb,     \
+                           ci_groups);                                                                                         \
+        if (strips_used) *strips_used = strips;                                                                                \
         return (int)hipGetLastError();                                                                                         \
     }
-    if (g.ks == 3 && g.stride == 1) LAUNCH(3, 1)
-    if (g.ks == 3 && g.stride == 2) LAUNCH(3, 2)
-    if (g.ks == 1 && g.stride == 1) LAUNCH(1, 1)
+#define LAUNCH_NB(KS_, S_)                                                                                                     \
+    {                                                                                                                          \
+        if (nt == 256) { if (nb == 1) LAUNCH(KS_, S_, 1, 256, false) if (nb == 2) LAUNCH(KS_, S_, 2, 256, false) if (nb == 3) LAUNCH(KS_, S_, 3, 256, false) } \
+        if (nt == 512 && !spec) { if (nb == 1) LAUNCH(KS_, S_, 1, 512, false) if (nb == 2) LAUNCH(KS_, S_, 2, 512, false) if (nb == 3) LAUNCH(KS_, S_, 3, 512, false) } \
+        if (nt == 512 && spec) { if (nb == 1) LAUNCH(KS_, S_, 1, 512, true) if (nb == 2) LAUNCH(KS_, S_, 2, 512, true) if (nb == 3) LAUNCH(KS_, S_, 3, 512, true) } \
+        return -3;                                                                                                             \
+    }
+    if (target < 256) return -3;
+    if (g.ks == 3 && g.stride == 1) LAUNCH_NB(3, 1)
+    if (g.ks == 3 && g.stride == 2) LAUNCH_NB(3, 2)
+    if (g.ks == 1 && g.stride == 1) LAUNCH_NB(1, 1)
+#undef LAUNCH_NB
 #undef LAUNCH
     return -2;
 }

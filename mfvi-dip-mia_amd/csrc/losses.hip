@@ -203,7 +203,78 @@ inline RngKey make_key(uint64_t seed, uint32_t domain, uint32_t stream, uint32_t
     return k;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// grad_finalize: reduce the per-(strip, sample) partial dW slabs written by the MFMA backward-weight kernels of ALL layers
+// of one backward pass and apply the reparameterisation chain rule (reparam_layers.py:26-37 under autograd):
+//   d mu[j] += sum_{s,k} P[s,k,j]          d rho[j] += sigmoid(rho[j]) * sum_k eps_k[j] * sum_s P[s,k,j]
+// eps_k[j] is re-derived from the counter RNG (same key as the forward draw).  A block owns GRAD_FIN_QUADS quads of 4
+// consecutive weights of one layer; its 4 waves split the samples and are summed through LDS.
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* __restrict__ table, int n_entries,
+                                                            const float* __restrict__ part_base, const float* __restrict__ rho,
+                                                            RngKey key, int sample_weights, int n_samples,
+                                                            float* __restrict__ dmu, float* __restrict__ drho)
+{
+    __shared__ float s_mu[3][GRAD_FIN_QUADS][4], s_rh[3][GRAD_FIN_QUADS][4];
+    int ei = 0;
+    while (ei + 1 < n_entries && table[ei + 1].first_block <= (int)blockIdx.x) ++ei;
+    const GradFinEntry e = table[ei];
+    const int t = threadIdx.x, ql = t & (GRAD_FIN_QUADS - 1), wv = t / GRAD_FIN_QUADS;
+    const int item = ((int)blockIdx.x - e.first_block) * GRAD_FIN_QUADS + ql;
+    const int nq_w = e.n_w >> 2, nq_b = (e.n_b + 3) >> 2;
+    const bool is_w = item < nq_w, is_b = !is_w && item < nq_w + nq_b;
+    const int quad = is_w ? item : item - nq_w;                    // quad index inside the weight / bias tensor
+    const long long col = is_w ? 4LL * quad : (long long)e.n_w + 4LL * quad;
+    const int nv = is_w ? 4 : min(4, e.n_b - 4 * quad);            // valid elements of the quad
+    float am[4] = {0.f, 0.f, 0.f, 0.f}, ar[4] = {0.f, 0.f, 0.f, 0.f};
+    if (is_w || is_b) {
+        const float* __restrict__ P = part_base + e.part_off + col;
+        for (int k = wv; k < n_samples; k += 4) {
+            float sk[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int sidx = 0; sidx < e.strips; ++sidx) {
+                const float* __restrict__ q = P + ((long long)sidx * n_samples + k) * e.stride;
+                if (is_w) { const float4 v = *reinterpret_cast<const float4*>(q); sk[0] += v.x; sk[1] += v.y; sk[2] += v.z; sk[3] += v.w; }
+                else for (int l = 0; l < nv; ++l) sk[l] += q[l];
+            }
+#pragma unroll
+            for (int l = 0; l < 4; ++l) am[l] += sk[l];
+            if (sample_weights) {
+                RngKey kw = key; kw.sample += (uint32_t)k;
+                kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id + (is_w ? 0 : 1));
+                float z[4]; spec_normal4(kw, (uint32_t)quad, z);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) ar[l] = __builtin_fmaf(sk[l], z[l], ar[l]);
+            }
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { s_mu[wv - 1][ql][l] = am[l]; s_rh[wv - 1][ql][l] = ar[l]; }
+    }
+    __syncthreads();
+    if (wv == 0 && (is_w || is_b)) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { am[l] += s_mu[w][ql][l]; ar[l] += s_rh[w][ql][l]; }
+        const long long j0 = (is_w ? e.w_off : e.b_off) + 4LL * quad;
+        for (int l = 0; l < nv; ++l) {
+            dmu[j0 + l] += am[l];
+            if (sample_weights) drho[j0 + l] += ar[l] * sigmoid_f(rho[j0 + l]);
+        }
+    }
+}
+
 }  // namespace
+
+int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
+                         int sample_weights, int n_samples, float* dmu, float* drho, hipStream_t st)
+{
+    if (n_entries < 1 || n_blocks < 1) return 0;
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
+                       n_samples, dmu, drho);
+    return (int)hipGetLastError();
+}
 
 extern "C" {
 

@@ -33,6 +33,8 @@ struct OpInfo {
     mfvi_op_desc d;
     ConvGeom g;
     long long scratch_off = -1;                // floats: padded input-gradient scratch of this conv
+    long long part_off = -1, part_stride = 0;  // floats: partial-dW slabs of the MFMA backward-weight kernel [strip][sample][stride]
+    int max_strips = 0;
 };
 
 inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
@@ -48,6 +50,8 @@ struct mfvi_plan {
     long long float_base = 0;                  // byte offset of the float arena
     long long total_bytes = 0;
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
+    GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
+    std::vector<GradFinEntry> fin_uploaded;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
     struct Rec { int op, pass; hipEvent_t a, b; };
     int prof_mode = 0, prof_op = -1, prof_pass = -1;      // 0 off, 1 every kernel, 2 only (prof_op, prof_pass)
@@ -158,7 +162,22 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         }
     const long long shared_off = take(shared_scratch);
     for (auto& o : p.ops) if (o.d.type == MFVI_OP_CONV && o.scratch_off < 0) o.scratch_off = shared_off;
+    // partial-dW slabs: up to ~4M floats per layer, at least one pixel strip
+    int n_conv = 0;
+    for (auto& o : p.ops)
+        if (o.d.type == MFVI_OP_CONV) {
+            ++n_conv;
+            const long long n_w = (long long)o.g.Cout * o.g.Cin * o.g.ks * o.g.ks;
+            o.part_stride = n_w + (o.g.b_off >= 0 ? align_up(o.g.Cout, 4) : 0);
+            const long long ms = (4LL << 20) / (o.part_stride * p.max_samples);
+            o.max_strips = (int)(ms < 1 ? 1 : (ms > 64 ? 64 : ms));
+            o.part_off = take(o.part_stride * p.max_samples * o.max_strips);
+        }
     p.total_bytes = p.float_base + fo * (long long)sizeof(float);
+    if (n_conv) {
+        const hipError_t e = hipMalloc((void**)&p.fin_dev, sizeof(GradFinEntry) * n_conv);
+        if (e != hipSuccess) return fail("plan: hipMalloc of the gradient table failed: %s", hipGetErrorString(e));
+    }
     p.n_entries = (int)table.size();
     if (p.n_entries) {
         hipError_t e = hipMalloc((void**)&p.table_dev, sizeof(BnGradEntry) * table.size());
@@ -169,7 +188,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     return true;
 }
 
-enum { PASS_FWD = 0, PASS_BWD_WEIGHT = 1, PASS_BWD_DATA = 2, PASS_FINALIZE = 3, PASS_CONCAT_BWD = 4 };
+enum { PASS_FWD = 0, PASS_BWD_WEIGHT = 1, PASS_BWD_DATA = 2, PASS_FINALIZE = 3, PASS_CONCAT_BWD = 4, PASS_GRAD_FINALIZE = 5 };
 
 struct ProfScope {
     mfvi_plan* p; hipStream_t st; bool on; hipEvent_t a, b; int op, pass;
@@ -245,7 +264,7 @@ int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_
     if (!tensors || !ops || !plan) { set_error("plan_create: null argument"); return -1; }
     mfvi_plan* p = new mfvi_plan();
     p->input = input_tensor; p->output = output_tensor; p->n_vi = n_vi; p->n_bn = n_bn; p->max_samples = max_samples;
-    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); delete p; *plan = nullptr; return -1; }
+    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); if (p->fin_dev) (void)hipFree(p->fin_dev); delete p; *plan = nullptr; return -1; }
     *plan = p;
     return 0;
 }
@@ -256,6 +275,7 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     for (auto& r : plan->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : plan->free_events) (void)hipEventDestroy(e);
     if (plan->table_dev) (void)hipFree(plan->table_dev);
+    if (plan->fin_dev) (void)hipFree(plan->fin_dev);
     delete plan;
 }
 
@@ -306,6 +326,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
+    std::vector<GradFinEntry> fin; int fin_blocks = 0;      // layers whose dW went to partial slabs in this pass
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) {
         const OpInfo& o = plan->ops[i];
         int rc = 0;
@@ -313,8 +334,17 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
             const GView gy = c.gview(o.d.out, dout);
             const TView xin = c.view(o.d.in0);
             { ProfScope ps(plan, i, PASS_BWD_WEIGHT, st);
-              rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st) : -2;
-              if (rc == -2) rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st); }
+              int strips = 0;
+              rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips, n_samples, st) : -2;
+              if (rc == 0) {
+                  GradFinEntry e{};
+                  e.w_off = o.g.w_off; e.b_off = o.g.b_off; e.part_off = o.part_off; e.stride = o.part_stride;
+                  e.n_w = o.g.Cout * o.g.Cin * o.g.ks * o.g.ks; e.n_b = o.g.b_off >= 0 ? o.g.Cout : 0; e.strips = strips; e.layer_id = o.g.layer_id;
+                  e.first_block = fin_blocks;
+                  fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS;
+                  fin.push_back(e);
+              }
+              if (rc == -2 || rc == -3) rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st); }
             const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
             if (!rc && need_dx) {
                 const int P = o.g.ks / 2;
@@ -349,6 +379,17 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                                       b.d.has_bn ? c.bsums() + b.stats_off : nullptr, n_samples, st);
         }
         if (rc) { if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    if (!fin.empty()) {
+        ProfScope ps(plan, -1, PASS_GRAD_FINALIZE, st);
+        const bool same = fin.size() == plan->fin_uploaded.size() && memcmp(fin.data(), plan->fin_uploaded.data(), sizeof(GradFinEntry) * fin.size()) == 0;
+        if (!same) {      // tilings change only when the plan is (re)tuned: the table is uploaded once in steady state
+            const hipError_t e = hipMemcpyAsync(plan->fin_dev, fin.data(), sizeof(GradFinEntry) * fin.size(), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) { set_error("backward: gradient table upload failed: %s", hipGetErrorString(e)); return (int)e; }
+            plan->fin_uploaded = fin;
+        }
+        const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho, key, sample_weights, n_samples, dmu, drho, st);
+        if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     if (plan->n_entries) {
         const int rc = launch_bn_param_grads(plan->table_dev, plan->n_entries, plan->max_c, c.bsums(), n_samples, dbn, st);
@@ -406,13 +447,13 @@ int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* o
 
 int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which)
 {
-    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 1 || plan->ops[op].d.type != MFVI_OP_CONV) return -1;
+    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 2 || plan->ops[op].d.type != MFVI_OP_CONV) return -1;
     return plan->ops[op].g.tune[which];
 }
 
 int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune)
 {
-    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 1 || tune < 0 || plan->ops[op].d.type != MFVI_OP_CONV) {
+    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 2 || tune < 0 || plan->ops[op].d.type != MFVI_OP_CONV) {
         set_error("plan_set_tune: bad arguments"); return -1; }
     plan->ops[op].g.tune[which] = tune;
     return 0;
@@ -450,37 +491,42 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
         const GView gy = c.gview(o.d.out, dout);
         const int P = o.g.ks / 2;
         const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
-        for (int which = 0; which < 2; ++which) {
+        const TView xin = c.view(o.d.in0);
+        for (int which = 0; which < 3; ++which) {
             if (which == 1 && o.d.in0 == plan->input) continue;
             auto launch = [&]() {
-                return which == 0 ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, mu, rho, key, 1, od, n_samples, st)
-                                  : launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, 1, c.farena() + o.scratch_off, per, n_samples, st);
+                if (which == 0) return launch_conv_fwd_mfma(xin, o.g, mu, rho, key, 1, od, n_samples, st);
+                if (which == 1) return launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, 1, c.farena() + o.scratch_off, per, n_samples, st);
+                return launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, nullptr, n_samples, st);
             };
+            // candidate tilings: fwd / bwd-data (mf, th, T) = fragments x tile rows x tiles per block;
+            //                    bwd-weight (nb, waves, target/256) = input tiles per block x waves x block-count target
+            std::vector<int> cands;
+            if (which < 2) { for (int th = 8; th <= 16; th += 8) for (int mf = 1; mf <= 4; ++mf) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | th << 8 | T << 16); }
+            else { for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16); }
             int best = 0; float best_ms = 1e30f;
-            for (int th = 8; th <= 16; th += 8)
-                for (int mf = 1; mf <= 4; ++mf)
-                    for (int T = 1; T <= 8; T *= 2) {
-                        o.g.tune[which] = mf | th << 8 | T << 16;
-                        rc = launch();                                   // warm-up; -2/-3: shape or tiling not served
-                        if (rc == -2) { T = 99; mf = 99; th = 99; continue; }
-                        if (rc == -3) continue;
-                        if (rc) { set_error("autotune: op %d launch failed: %s", (int)i, rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad arguments"); goto done; }
-                        (void)hipEventRecord(ea, st);
-                        for (int r = 0; r < reps && !rc; ++r) rc = launch();
-                        (void)hipEventRecord(eb, st);
-                        float ms = 0.f;
-                        e = hipEventSynchronize(eb);
-                        if (e == hipSuccess) e = hipEventElapsedTime(&ms, ea, eb);
-                        if (rc || e != hipSuccess) { set_error("autotune: op %d timing failed: %s", (int)i, hipGetErrorString(rc ? (hipError_t)rc : e)); rc = rc ? rc : (int)e; goto done; }
-                        if (ms < best_ms) { best_ms = ms; best = o.g.tune[which]; }
-                    }
+            for (int cand : cands) {
+                o.g.tune[which] = cand;
+                rc = launch();                                   // warm-up; -2/-3: shape or tiling not served
+                if (rc == -2) break;
+                if (rc == -3) continue;
+                if (rc) { set_error("autotune: op %d launch failed: %s", (int)i, rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad arguments"); goto done; }
+                (void)hipEventRecord(ea, st);
+                for (int r = 0; r < reps && !rc; ++r) rc = launch();
+                (void)hipEventRecord(eb, st);
+                float ms = 0.f;
+                e = hipEventSynchronize(eb);
+                if (e == hipSuccess) e = hipEventElapsedTime(&ms, ea, eb);
+                if (rc || e != hipSuccess) { set_error("autotune: op %d timing failed: %s", (int)i, hipGetErrorString(rc ? (hipError_t)rc : e)); rc = rc ? rc : (int)e; goto done; }
+                if (ms < best_ms) { best_ms = ms; best = cand; }
+            }
             o.g.tune[which] = best;
             rc = 0;
         }
     }
 done:
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
-    if (rc) for (auto& o : plan->ops) { o.g.tune[0] = 0; o.g.tune[1] = 0; }
+    if (rc) for (auto& o : plan->ops) { o.g.tune[0] = 0; o.g.tune[1] = 0; o.g.tune[2] = 0; }
     return rc;
 }
 

@@ -113,10 +113,10 @@ class Plan:
         self.tuned = True
 
     def tunes(self):
-        """-> {op index: (forward tiling, backward-data tiling)} as (mf, th, T) triples; None = heuristic."""
+        """-> {op index: (forward, backward-data, backward-weight tiling)} as triples; None = heuristic."""
         dec = lambda v: None if v <= 0 else (v & 255, (v >> 8) & 255, (v >> 16) & 255)
         lib = L.lib()
-        return {i: (dec(lib.mfvi_plan_get_tune(self.handle, i, 0)), dec(lib.mfvi_plan_get_tune(self.handle, i, 1)))
+        return {i: tuple(dec(lib.mfvi_plan_get_tune(self.handle, i, w)) for w in range(3))
                 for i, o in enumerate(self.prog.ops) if o["type"] == L.OP_CONV}
 
     def profile(self, mode, op=-1, pass_=-1):
