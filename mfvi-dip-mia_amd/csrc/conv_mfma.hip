@@ -54,7 +54,6 @@ struct MfmaArgs {
     RngKey key; int sample_weights;
     OutDesc out; float* dxp; long long dxp_sstride;
     int tiles_x, n_tiles, tiles_per_block;
-    int dbg;      // MFVI_DBG bit mask (experiments only): 1 skip global loads, 2 skip MFMA, 4 skip LDS stores, 8 skip epilogue
 };
 
 template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS>
@@ -175,20 +174,22 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
         const float* __restrict__ xsrc = MODE == 0 ? A.xin.data + (long long)k * A.xin.sstride : A.gin.ga + (long long)k * A.gin.gstride;
         const float* __restrict__ ysrc = (MODE == 1 && A.gin.y) ? A.gin.y + (long long)k * A.gin.ystride : nullptr;
         const int xact = A.xin.act; const float xslope = A.xin.slope;
-        constexpr int NPOS = (IN_TH * IN_TW + 255) / 256;       // fixed positions of the staged tile owned by this thread
-        int goff[NPOS], loff[NPOS];
-#pragma unroll
-        for (int j = 0; j < NPOS; ++j) {
-            const int p = t + 256 * j, iy = p / IN_TW, ix = p - iy * IN_TW;
-            loff[j] = p < IN_TH * IN_TW ? iy * PITCH + ix : -1;
-        }
+        // Producer wave pw stages channels {pw*CPW .. pw*CPW+CPW-1} of each 8-channel chunk at positions lane + 64*j of the
+        // tile window: the channel is wave-uniform (its BN constants are read once per chunk, not per element) and the LDS
+        // address of position p is p itself (PITCH == IN_TW), so an element costs a transform and one ds_write.
+        constexpr int CPW = CC / 4;
+        constexpr int NPOSW = IN_TH * IN_TW;                     // positions of the staged window
+        constexpr int NPX = (NPOSW + 63) / 64;
+        static_assert(PITCH == IN_TW, "window rows are stored back to back");
+        const int pw = wv;
+        int goff[NPX];                                           // global offset of position lane + 64*j; -1 = stage a zero
         auto set_tile = [&](int tile) {
             const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
             const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
             const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (KS - 1);
 #pragma unroll
-            for (int j = 0; j < NPOS; ++j) {
-                const int p = t + 256 * j, iy = p / IN_TW, ix = p - iy * IN_TW;
+            for (int j = 0; j < NPX; ++j) {
+                const int p = min(lane + 64 * j, NPOSW - 1), iy = p / IN_TW, ix = p - iy * IN_TW;
                 int gy = sy0 + iy, gx = sx0 + ix;
                 if (MODE == 0) {
                     gy = reflect_idx(gy, H); gx = reflect_idx(gx, W);
@@ -201,39 +202,40 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                     } else
                         goff[j] = (gy >= 0 && gy < SH && gx >= 0 && gx < SW) ? gy * SW + gx : -1;   // zero padding
                 }
-                if (loff[j] < 0) goff[j] = -1;
             }
         };
-        float xr[NPOS][CC], yr[MODE == 1 ? NPOS : 1][MODE == 1 ? CC : 1];
-        unsigned okmask = 0;
+        float xr[CPW][NPX], yr[MODE == 1 ? CPW : 1][MODE == 1 ? NPX : 1];
         // Branch-free: every load uses a valid (clamped) address; invalid positions / channels are zeroed at the LDS store.
         auto prefetch = [&](int c0) {
-            okmask = 0;
 #pragma unroll
-            for (int j = 0; j < NPOS; ++j) {
-                if (goff[j] >= 0) okmask |= 1u << j;
-                const int gsafe = max(goff[j], 0);
+            for (int i = 0; i < CPW; ++i) {
+                const long long cb = (long long)min(c0 + pw * CPW + i, RED - 1) * SHW;
 #pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    const int off = min(c0 + c, RED - 1) * SHW + gsafe;
-                    xr[j][c] = (A.dbg & 1) ? 1.0f : xsrc[off];
-                    if (MODE == 1) yr[j][c] = ysrc ? ysrc[off] : 0.f;
+                for (int j = 0; j < NPX; ++j) {
+                    const long long off = cb + max(goff[j], 0);
+                    xr[i][j] = xsrc[off];
+                    if (MODE == 1) yr[i][j] = ysrc ? ysrc[off] : 0.f;
                 }
             }
         };
         auto store = [&](int c0, float* __restrict__ dst) {      // registers -> LDS with the deferred transform
             const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
 #pragma unroll
-            for (int j = 0; j < NPOS; ++j) {
-                if (loff[j] < 0) continue;
-                const bool okj = (okmask >> j) & 1u;
+            for (int i = 0; i < CPW; ++i) {
+                const int cl = pw * CPW + i;
+                if (cl >= cc4) continue;                          // wave-uniform: channel beyond the padded chunk
+                const bool live = cl < cc;
+                const int ch = min(c0 + cl, RED - 1);
+                ChanFwd kf; ChanBwd kb;
+                if (MODE == 0) kf = s_ch[ch]; else kb = s_chb[ch];
 #pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    float v = 0.f;
-                    if (MODE == 0) v = apply_fwd(s_ch[min(c0 + c, RED - 1)], xr[j][c], xact, xslope);
-                    else v = ysrc ? apply_bwd(s_chb[min(c0 + c, RED - 1)], xr[j][c], yr[j][c]) : xr[j][c];
-                    if (c >= cc || (MODE == 1 && !okj)) v = 0.f;
-                    if (c < cc4 && !(A.dbg & 4)) dst[c * PLANE + loff[j]] = v;
+                for (int j = 0; j < NPX; ++j) {
+                    const int p = lane + 64 * j;
+                    float v;
+                    if (MODE == 0) v = apply_fwd(kf, xr[i][j], xact, xslope);
+                    else v = ysrc ? apply_bwd(kb, xr[i][j], yr[i][j]) : xr[i][j];
+                    if (!live || (MODE == 1 && goff[j] < 0)) v = 0.f;
+                    if (64 * (j + 1) <= NPOSW || p < NPOSW) dst[cl * PLANE + p] = v;
                 }
             }
         };
@@ -309,9 +311,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][i], b[q & 1][f], acc[i][f], 0, 0, 0);
                 }
             };
-            if (!(A.dbg & 2)) { if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{}); }
+            if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
 
-            if (ci == n_chunks - 1 && !(A.dbg & 8)) {
+            if (ci == n_chunks - 1) {
                 // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg
                 const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
                 if (MODE == 0) {
@@ -393,8 +395,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     const int OH = MODE == 0 ? g.Ho : g.H + 2 * P, OW = MODE == 0 ? g.Wo : g.W + 2 * P;    // output pixel domain
     const int MOUT = MODE == 0 ? g.Cout : g.Cin, RED = MODE == 0 ? g.Cin : g.Cout;
     const int RED4 = (RED + 3) & ~3;
-    static const int dbg = [] { const char* e = getenv("MFVI_DBG"); return e ? atoi(e) : 0; }();
-    MfmaArgs A{xin, gin, g, mu, rho, key, sample_weights, out, dxp, dxp_sstride, 0, 0, 1, dbg};
+    MfmaArgs A{xin, gin, g, mu, rho, key, sample_weights, out, dxp, dxp_sstride, 0, 0, 1};
 
     // Pick the largest tile that still gives the chip enough blocks: big tiles amortise the in-kernel weight sampling
     // (each sampled weight is reused by every pixel of the tile), small ones keep 256 CUs busy.  When the whole slab of a
