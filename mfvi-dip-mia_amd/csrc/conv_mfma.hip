@@ -270,11 +270,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
         const int aoff = l4 * CTP + l15;
         const int wtap = REDP * CTP;
         f32x4 acc[MF][NF];
-        double ssum[MF][4], ssq[MF][4];        // BN statistics of this wave's outputs, accumulated over all tiles of the block
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.0; ssq[i][r] = 0.0; }
+        const bool do_stats = MODE == 0 && A.out.stats != nullptr;
+        // BN statistics of this wave's outputs: float partial sums per tile, folded into the wave's fp64 slots in LDS
+        if (do_stats && lane < CT) { s_red[wv][lane][0] = 0.0; s_red[wv][lane][1] = 0.0; }
         __syncthreads();                                  // (S0)
         lds_barrier();                                    // (A)
         for (int it = 0; it < n_iters; ++it) {
@@ -314,42 +312,63 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
 
             if (ci == n_chunks - 1) {
-                // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg
+                // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg.
+                // 32-bit element offsets from a wave-uniform base keep the address math out of the VGPR budget.
                 const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
                 if (MODE == 0) {
-                    float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride;
                     const int HWo = g.Ho * g.Wo;
+                    float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HWo;
+                    const int rowbase = l4 * 4 * HWo;
+                    float fs[MF][4], fq[MF][4];
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { fs[i][r] = 0.f; fq[i][r] = 0.f; }
 #pragma unroll
                     for (int i = 0; i < MF; ++i) {
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
                             const int oy = py0 + wv * (TH / 4) + (f >> 1), ox = px0 + (f & 1) * 16 + l15;
                             if (oy < g.Ho && ox < g.Wo) {
+                                const int pofs = rowbase + oy * g.Wo + ox;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int ml = i * 16 + l4 * 4 + r;
                                     if (ml < mt) {
                                         const float v = acc[i][f][r] + s_bias[ml];
-                                        yout[(long long)(m0 + ml) * HWo + oy * g.Wo + ox] = v;
-                                        ssum[i][r] += (double)v; ssq[i][r] += (double)v * (double)v;
+                                        yout[(i * 16 + r) * HWo + pofs] = v;
+                                        fs[i][r] += v; fq[i][r] = __builtin_fmaf(v, v, fq[i][r]);
                                     }
                                 }
                             }
                         }
                     }
+                    if (do_stats) {
+#pragma unroll
+                        for (int i = 0; i < MF; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float a = fs[i][r], b = fq[i][r];
+#pragma unroll
+                                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                                if (l15 == 0) { s_red[wv][i * 16 + l4 * 4 + r][0] += (double)a; s_red[wv][i * 16 + l4 * 4 + r][1] += (double)b; }
+                            }
+                    }
                 } else {
-                    const int Hp = g.H + 2 * P, Wp = g.W + 2 * P;
-                    float* __restrict__ o = A.dxp + (long long)k * A.dxp_sstride;
+                    const int Hp = g.H + 2 * P, Wp = g.W + 2 * P, HWp = Hp * Wp;
+                    float* __restrict__ o = A.dxp + (long long)k * A.dxp_sstride + (long long)m0 * HWp;
+                    const int rowbase = l4 * 4 * HWp;
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
                             const int pr = py0 + wv * (TH / 4) + (f >> 1), pc = px0 + (f & 1) * 16 + l15;
                             if (pr < Hp && pc < Wp) {
+                                const int pofs = rowbase + pr * Wp + pc;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int ml = i * 16 + l4 * 4 + r;
-                                    if (ml < mt) o[(long long)(m0 + ml) * Hp * Wp + pr * Wp + pc] = acc[i][f][r];
+                                    if (ml < mt) o[(i * 16 + r) * HWp + pofs] = acc[i][f][r];
                                 }
                             }
                         }
@@ -357,18 +376,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             }
             lds_barrier();
         }
-        if (MODE == 0 && A.out.stats != nullptr) {
+        if (do_stats) {
             // One fp64 atomic per (channel, moment) per BLOCK: same-address float atomics serialise at the memory side
             // (~0.2 us each), so per-tile or per-wave atomics would dominate the kernel.
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double a = ssum[i][r], b = ssq[i][r];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-                    if (l15 == 0) { s_red[wv][i * 16 + l4 * 4 + r][0] = a; s_red[wv][i * 16 + l4 * 4 + r][1] = b; }
-                }
             __syncthreads();                              // (Z)
             if (t < CT * 2) {
                 const int q = t >> 1, which = t & 1;
@@ -456,6 +466,7 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, co
                          OutDesc out, int n_samples, hipStream_t st)
 {
     if (g.Cin > MFVI_MAX_C || (g.Cin & 3) || (g.w_off & 3)) return -2;      // Philox blocks must tile every weight row
+    if ((long long)g.Cout * g.Ho * g.Wo >= (1LL << 31)) return -2;          // the epilogue uses 32-bit element offsets per sample
     GView none{};
     if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
     if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
@@ -467,6 +478,7 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* m
                               float* dxp, long long dxp_sstride, int n_samples, hipStream_t st)
 {
     if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks == 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
+    if ((long long)g.Cin * (g.H + 2) * (g.W + 2) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
     TView none{}; OutDesc od{};
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
     if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
