@@ -232,6 +232,10 @@ __device__ __forceinline__ double block_sum_d(double v, double* red)
 // ------------------------------------------------------------------------------------------------
 // Host-side launch plumbing shared by the .hip files
 // ------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Give XCD j the j-th contiguous band of
+// the n tile groups, so blocks that share halo rows / cache lines share an L2 (identity when n is not a multiple of 8).
+__device__ __forceinline__ int xcd_band(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+
 struct ConvGeom {
     int Cin, Cout, H, W, Ho, Wo, ks, stride;
     long long w_off, b_off;    // into mu / rho

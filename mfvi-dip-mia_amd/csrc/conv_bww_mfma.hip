@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         }
     };
 
-    const int tile_begin = blockIdx.x * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
+    const int tile_begin = xcd_band(blockIdx.x, gridDim.x) * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
     if constexpr (SPEC) {
         if (producer) {
             // Producer wave pw stages input channels [pw*CPW, (pw+1)*CPW) and gradient channels [pw*4, pw*4+4): the channel is

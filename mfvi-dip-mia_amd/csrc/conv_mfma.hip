@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             }
     };
 
-    const int tile_begin = blockIdx.x * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
+    const int tile_begin = xcd_band(blockIdx.x, gridDim.x) * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
     if (tile_begin >= tile_end) return;
     const int n_iters = (tile_end - tile_begin) * n_chunks;
 

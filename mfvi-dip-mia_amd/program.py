@@ -102,15 +102,39 @@ class Plan:
                                       int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(dout), L.ptr(dmu), L.ptr(drho),
                                       L.ptr(dbn), L.ptr(dz), L.stream_ptr()))
 
-    def autotune(self, mu, rho, bn, z, n_samples=None):
-        """Time the valid MFMA tilings of every conv op on this device and keep the fastest (results unchanged)."""
-        import torch
+    def autotune(self, mu, rho, bn, z, n_samples=None, cache=None):
+        """Time the valid MFMA tilings of every conv op on this device and keep the fastest (results unchanged).
+        cache: optional JSON path — tilings found earlier for the same program / sample count are reused (and a fresh
+        search is written there), e.g. to keep a profiled run free of the search's launches."""
+        import json, os, torch
         n = n_samples or self.max_samples
+        sig = "%d:%s" % (n, ";".join("%d,%d,%d,%d,%d" % (o["type"], o["ksize"], o["stride"], self.prog.tensors[o["out"]]["C"],
+                                                         self.prog.tensors[o["out"]]["H"] * self.prog.tensors[o["out"]]["W"]) for o in self.prog.ops))
+        cache = cache or os.environ.get("MFVI_TUNE_CACHE")
+        if cache and os.path.exists(cache):
+            try:
+                saved = json.load(open(cache))
+                if saved.get("sig") == sig:
+                    for i, tri in saved["tunes"].items():
+                        for w, v in enumerate(tri):
+                            L.check(L.lib().mfvi_plan_set_tune(self.handle, int(i), w, int(v)))
+                    self.tuned = True
+                    return
+            except (ValueError, KeyError, OSError):
+                pass
         out_scratch = torch.empty(2 * n * self.out_shape[0] * self.out_shape[1] * self.out_shape[2], dtype=torch.float32, device="cuda")
         grad_scratch = torch.empty(2 * self.prog.n_vi + self.prog.n_bn, dtype=torch.float32, device="cuda")
         L.check(L.lib().mfvi_plan_autotune(self.handle, L.ptr(mu), L.ptr(rho), L.ptr(bn), L.ptr(z), n, L.ptr(self.workspace),
                                            L.ptr(out_scratch), L.ptr(grad_scratch), L.stream_ptr()))
         self.tuned = True
+        if cache:
+            lib = L.lib()
+            raw = {str(i): [max(lib.mfvi_plan_get_tune(self.handle, i, w), 0) for w in range(3)]
+                   for i, o in enumerate(self.prog.ops) if o["type"] == L.OP_CONV}
+            try:
+                json.dump({"sig": sig, "tunes": raw}, open(cache, "w"))
+            except OSError:
+                pass
 
     def tunes(self):
         """-> {op index: (forward, backward-data, backward-weight tiling)} as triples; None = heuristic."""
