@@ -232,9 +232,20 @@ __device__ __forceinline__ double block_sum_d(double v, double* red)
 // ------------------------------------------------------------------------------------------------
 // Host-side launch plumbing shared by the .hip files
 // ------------------------------------------------------------------------------------------------
-// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Give XCD j the j-th contiguous band of
-// the n tile groups, so blocks that share halo rows / cache lines share an L2 (identity when n is not a multiple of 8).
-__device__ __forceinline__ int xcd_band(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Decode a 1-D launch of nx*ny*nz
+// blocks so that (a) the ny blocks that read the same input tile (output-channel tiles / channel-pair tiles of one spatial
+// unit) run back to back on ONE XCD and (b) each XCD owns a contiguous band of (sample, spatial) units, so halo rows are
+// re-read from its L2, not from HBM.  Falls back to the plain order when nx*nz is not a multiple of 8.
+__device__ __forceinline__ void xcd_decode(int L, int nx, int ny, int nz, int& bx, int& by, int& bz)
+{
+    const int units = nx * nz;
+    if ((units & 7) == 0) {
+        const int xcd = L & 7, slot = L >> 3;
+        by = slot % ny;
+        const int u = xcd * (units >> 3) + slot / ny;
+        bx = u % nx; bz = u / nx;
+    } else { bx = L % nx; by = (L / nx) % ny; bz = L / (nx * ny); }
+}
 
 struct ConvGeom {
     int Cin, Cout, H, W, Ho, Wo, ks, stride;

@@ -42,7 +42,7 @@ struct WCfg {
 template <int KS, int STRIDE, int NB, int NT, bool SPEC>
 __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, ConvGeom g, float* __restrict__ part,
                                                            long long part_stride, int tiles_x, int n_tiles,
-                                                           int tiles_per_block, int ci_groups)
+                                                           int tiles_per_block, int ci_groups, int nx, int ny, int nz)
 {
     using Cfg = WCfg<KS, STRIDE, NB, NT>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH, KK = Cfg::KK, P = KS / 2, IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW;
@@ -60,8 +60,9 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, l4 = lane >> 4;
     const bool producer = SPEC && t >= NS;
     const int ts = SPEC ? (t & (NS - 1)) : t;         // staging slot of this thread
-    const int k = blockIdx.z;
-    const int co0 = (blockIdx.y / ci_groups) * 16, ci0 = (blockIdx.y % ci_groups) * CIB;
+    int bx, by, k;
+    xcd_decode(blockIdx.x, nx, ny, nz, bx, by, k);
+    const int co0 = (by / ci_groups) * 16, ci0 = (by % ci_groups) * CIB;
     const int Cin = g.Cin, Cout = g.Cout, H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
     const bool do_bias = (ci0 == 0) && (g.b_off >= 0);
     const int cot = min(16, Cout - co0), cit = min(CIB, Cin - ci0);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         }
     };
 
-    const int tile_begin = xcd_band(blockIdx.x, gridDim.x) * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
+    const int tile_begin = bx * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
     if constexpr (SPEC) {
         if (producer) {
             // Producer wave pw stages input channels [pw*CPW, (pw+1)*CPW) and gradient channels [pw*4, pw*4+4): the channel is
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
 
     // ---- this block's partial sums -> its slab (contiguous rows; every (strip, sample) slab is covered exactly once) ----
     const int len = cit * KK;
-    float* __restrict__ o = part + ((long long)blockIdx.x * gridDim.z + k) * part_stride;
+    float* __restrict__ o = part + ((long long)bx * nz + k) * part_stride;
     for (int idx = t; idx < 16 * len; idx += NT) {
         const int r = idx / len, rel = idx - r * len, co = co0 + r;
         if (co < Cout) o[((long long)co * Cin + ci0) * KK + rel] = s_dw[r * ROW + rel];
@@ -320,9 +321,8 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (attr != hipSuccess) return (int)attr;                                                                          \
         }                                                                                                                      \
-        dim3 grid(strips, co_tiles * ci_groups, n_samples);                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(NT_), lds_bytes, st, in, gy, g, part.base, part.stride, tiles_x, n_tiles, tpb,     \
-                           ci_groups);                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(strips * co_tiles * ci_groups * n_samples), dim3(NT_), lds_bytes, st, in, gy, g, part.base, \
+                           part.stride, tiles_x, n_tiles, tpb, ci_groups, strips, co_tiles * ci_groups, n_samples);            \
         if (strips_used) *strips_used = strips;                                                                                \
         return (int)hipGetLastError();                                                                                         \
     }

@@ -54,6 +54,7 @@ struct MfmaArgs {
     RngKey key; int sample_weights;
     OutDesc out; float* dxp; long long dxp_sstride;
     int tiles_x, n_tiles, tiles_per_block;
+    int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
 };
 
 template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS>
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
     const bool producer = tid >= 256;
     const int t = tid & 255, lane = t & 63, wv = t >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int k = blockIdx.z;
-    const int m0 = blockIdx.y * CT;                                  // first output channel of the block
+    int bx, by, k;
+    xcd_decode(blockIdx.x, A.nx, A.ny, A.nz, bx, by, k);
+    const int m0 = by * CT;                                          // first output channel of the block
 
     // MODE 0: reduce over cin, outputs = cout.   MODE 1: reduce over cout, outputs = cin.
     const int RED = MODE == 0 ? g.Cin : g.Cout;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             }
     };
 
-    const int tile_begin = xcd_band(blockIdx.x, gridDim.x) * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
+    const int tile_begin = bx * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
     if (tile_begin >= tile_end) return;
     const int n_iters = (tile_end - tile_begin) * n_chunks;
 
@@ -430,13 +432,13 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         if (forced_T > 0) T = forced_T;                                                                                    \
         if (T >= 2 && ws_bytes <= 40 * 1024) {                                                                             \
             A.tiles_per_block = T;                                                                                         \
-            dim3 grid((A.n_tiles + T - 1) / T, my, n_samples);                                                             \
-            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true>), grid, dim3(512), ws_bytes, st, A);      \
+            A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
         } else {                                                                                                           \
             if (forced_T > 1) return -3;                                                                                   \
             A.tiles_per_block = 1;                                                                                         \
-            dim3 grid(A.n_tiles, my, n_samples);                                                                           \
-            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false>), grid, dim3(512), ck_bytes, st, A);     \
+            A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }
