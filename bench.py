@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 DEN = dict(temp=5.656911698337764e-07, sigma=1.4616642493692077e-05, lr=1e-3, seed=1, p_sigma=0.1, input_depth=16)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector == FP32-input MFMA peak
-PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd", 5: "grad_finalize"}
+PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd", 5: "grad_finalize", 6: "sample_weights"}
 
 
 def conv_cost(prog, op_index, n_samples):

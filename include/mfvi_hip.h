@@ -87,7 +87,7 @@ int mfvi_plan_read_tensor(const mfvi_plan* plan, const void* workspace, int tens
 
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around the plan's launches.
  * mode 0: off; 1: every kernel; 2: only kernel (op, pass).  pass: 0 forward, 1 backward-weight, 2 backward-data,
- * 3 fold/finalize, 4 concat backward, 5 gradient finalize (op -1).  mfvi_plan_profile_read synchronises the recorded events, writes up to
+ * 3 fold/finalize, 4 concat backward, 5 gradient finalize, 6 weight sampling (both op -1).  mfvi_plan_profile_read synchronises the recorded events, writes up to
  * `capacity` records (op index, pass, milliseconds) and clears the log. */
 int mfvi_plan_profile(mfvi_plan* plan, int mode, int op, int pass);
 int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* ops, int* passes, float* ms);

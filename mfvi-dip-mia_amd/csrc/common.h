@@ -268,10 +268,15 @@ int launch_conv_bwd_data(const GView& gy, const ConvGeom& g, const float* mu, co
 int launch_conv_bwd_weight(const TView& in, const GView& gy, const ConvGeom& g, const float* rho, RngKey key, int sample_weights,
                            float* dmu, float* drho, int n_samples, hipStream_t st);
 // MFMA variants (conv_mfma.hip): return -2 when the shape is not served and the generic kernel must run.
-int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
-                         OutDesc out, int n_samples, hipStream_t st);
-int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
-                              float* dxp, long long dxp_sstride, int n_samples, hipStream_t st);
+// w: weights of sample 0, sample k at w + k*wstride (plan.hip: the buffer filled by launch_sample_weights, or mu with stride 0)
+int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
+int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w, long long wstride, float* dxp, long long dxp_sstride,
+                              int n_samples, hipStream_t st);
+// One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
+struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
+int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const float* mu, const float* rho, RngKey key,
+                          int n_samples, float* wsamp, long long wstride, hipStream_t st);
+constexpr int SAMPLE_QUADS = 256;       // weight quads per block of the sampling kernel
 // The MFMA backward-weight kernel writes per-(pixel strip, sample) partial sums of dW (and of the bias gradient) with plain
 // stores: part.base[(strip * n_samples + k) * part.stride + j], j < n_w weights then n_b biases; launch_grad_finalize reduces
 // them, multiplies by eps * sigmoid(rho) per sample and accumulates into dmu / drho — no atomics, deterministic.

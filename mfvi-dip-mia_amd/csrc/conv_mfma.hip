@@ -8,8 +8,8 @@
 //   MODE 1 (backward-data, stride 1):            m = cin,  k = (cout, flipped tap), B = zero-padded dy (formed on
 //                                                 load from ga / y / BN sums), output = gradient wrt the PADDED input
 //
-// Per 256-thread block: 32 x TH pixel tiles x (16*MF) output channels.  The block SAMPLES its weight slab
-// w = mu + softplus(rho)*eps into LDS (eps from Philox, never stored in HBM) —
+// Per 512-thread block: 32 x TH pixel tiles x (16*MF) output channels.  The block copies its slab of the
+// weights of sample k (w = mu + softplus(rho)*eps, drawn once per pass by sample_weights_kernel) into LDS —
 //   WS = true  (weight-stationary): the whole slab [taps][all reduction channels][16*MF] once, then it walks several
 //               pixel tiles, so every sampled weight is reused by thousands of pixels (high-resolution layers);
 //   WS = false: one CC-channel chunk at a time inside the reduction loop (slabs too big for LDS / few tiles).
@@ -50,8 +50,7 @@ static_assert(pitch16(16) == 16 && pitch16(32) == 48 && pitch16(64) == 80 && pit
 
 struct MfmaArgs {
     TView xin; GView gin; ConvGeom g;
-    const float* mu; const float* rho;
-    RngKey key; int sample_weights;
+    const float* w; long long wstride;     // weights of sample k at w + k*wstride (drawn by sample_weights_kernel; stride 0 = mu)
     OutDesc out; float* dxp; long long dxp_sstride;
     int tiles_x, n_tiles, tiles_per_block;
     int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
@@ -79,8 +78,6 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
     __shared__ double s_red[4][CT][2];
 
     const ConvGeom& g = A.g;
-    const float* __restrict__ mu = A.mu; const float* __restrict__ rho = A.rho;
-    const int sample_weights = A.sample_weights;
     const int tid = threadIdx.x;
     const bool producer = tid >= 256;
     const int t = tid & 255, lane = t & 63, wv = t >> 6;
@@ -96,50 +93,35 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
     const int REDP = WS ? ((RED + 3) & ~3) : CC;                     // reduction-channel pitch of s_w
     const int n_chunks = (RED + CC - 1) / CC;
 
-    RngKey kw = A.key; kw.sample += (uint32_t)k; kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * g.layer_id);
+    const float* __restrict__ wk = A.w + (long long)k * A.wstride;
 
     if (MODE == 0) {
         for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c);
         if (tid < CT) {
-            const int co = m0 + tid; float b = 0.f;
-            if (co < g.Cout && g.b_off >= 0) {
-                b = mu[g.b_off + co];
-                if (sample_weights) {
-                    RngKey kb = kw; kb.stream += 1u;
-                    float z[4]; spec_normal4(kb, (uint32_t)(co >> 2), z);
-                    b += softplus_f(rho[g.b_off + co]) * z[co & 3];
-                }
-            }
+            const int co = m0 + tid;
+            const float b = (co < g.Cout && g.b_off >= 0) ? wk[g.b_off + co] : 0.f;
             s_bias[tid] = b;
         }
     } else {
         for (int c = tid; c < g.Cout; c += 512) s_chb[c] = chan_bwd(A.gin, k, c);
     }
 
-    // Sample the weight slab of reduction channels [c0, c0+cc) into wdst[tap][kbase + kk][m] with `nthr` threads.
+    // Copy the weight slab of reduction channels [c0, c0+cc) of this sample into wdst[tap][kbase + kk][m] with `nthr` threads.
     //   MODE 0: rows = output channel m, global range ((m0+m)*Cin + c0)*KK + [0, cc*KK),   element -> (kk, tap)
     //   MODE 1: rows = reduction channel kk, range ((c0+kk)*Cin + m0)*KK + [0, mt*KK),     element -> (m, flipped tap)
-    // The launcher guarantees Cin % 4 == 0 and w_off % 4 == 0, so every row range is a whole number of aligned Philox
-    // blocks (4 consecutive weights): one float4 of mu, one of rho and one Philox call per block.
-    auto sample_slab = [&](int c0, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
+    // The launcher guarantees Cin % 4 == 0 and w_off % 4 == 0, so every row range is a whole number of aligned float4.
+    auto load_slab = [&](int c0, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
         const int rows = MODE == 0 ? CT : cc4;
         const int valid_rows = MODE == 0 ? mt : cc;
         const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
-        const float4* __restrict__ mu4 = reinterpret_cast<const float4*>(mu + g.w_off);
-        const float4* __restrict__ rho4 = reinterpret_cast<const float4*>(rho + g.w_off);
+        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wk + g.w_off);
         for (int idx = th; idx < rows * G; idx += nthr) {
             const int row = idx / G, gi = idx - row * G;
             float w[4] = {0.f, 0.f, 0.f, 0.f};
             if (row < valid_rows) {
                 const int blk = (MODE == 0 ? (((m0 + row) * g.Cin + c0) * KK) : (((c0 + row) * g.Cin + m0) * KK)) / 4 + gi;
-                const float4 a = mu4[blk];
+                const float4 a = w4[blk];
                 w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-                if (sample_weights) {
-                    const float4 b = rho4[blk];
-                    float z[4]; spec_normal4(kw, (uint32_t)blk, z);
-                    w[0] = __builtin_fmaf(softplus_fast(b.x), z[0], w[0]); w[1] = __builtin_fmaf(softplus_fast(b.y), z[1], w[1]);
-                    w[2] = __builtin_fmaf(softplus_fast(b.z), z[2], w[2]); w[3] = __builtin_fmaf(softplus_fast(b.w), z[3], w[3]);
-                }
             }
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
@@ -165,7 +147,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
     const int n_iters = (tile_end - tile_begin) * n_chunks;
 
     if (WS)       // the whole slab, once, by all 8 waves
-        for (int c0 = 0; c0 < RED; c0 += CC) { const int cc = min(CC, RED - c0); sample_slab(c0, cc, (cc + 3) & ~3, c0, s_w, tid, 512); }
+        for (int c0 = 0; c0 < RED; c0 += CC) { const int cc = min(CC, RED - c0); load_slab(c0, cc, (cc + 3) & ~3, c0, s_w, tid, 512); }
 
     const int H = g.H, W = g.W;
     const int SH = MODE == 0 ? H : g.Ho, SW = MODE == 0 ? W : g.Wo;
@@ -248,14 +230,14 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
         set_tile(ptile); prefetch(pc0);
         __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
         store(pc0, s_x[0]);
-        if (!WS) { const int cc = min(CC, RED - pc0); sample_slab(pc0, cc, (cc + 3) & ~3, 0, s_w, t, 256); }
+        if (!WS) { const int cc = min(CC, RED - pc0); load_slab(pc0, cc, (cc + 3) & ~3, 0, s_w, t, 256); }
         if (n_iters > 1) { int nt, nc; chunk_of(1, nt, nc); if (nt != ptile) { set_tile(nt); ptile = nt; } prefetch(nc); }
         lds_barrier();                                    // (A) chunk 0 published
         for (int it = 0; it < n_iters; ++it) {
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 store(nc, s_x[(it + 1) & 1]);
-                if (!WS) { const int cc = min(CC, RED - nc); sample_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
+                if (!WS) { const int cc = min(CC, RED - nc); load_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
                 if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
             }
             lds_barrier();
@@ -400,14 +382,14 @@ int env_tune()
 }
 
 template <int KS, int STRIDE, int MODE>
-int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const float* mu, const float* rho, RngKey key,
-                   int sample_weights, OutDesc out, float* dxp, long long dxp_sstride, int n_samples, hipStream_t st)
+int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const float* w, long long wstride, OutDesc out, float* dxp,
+                   long long dxp_sstride, int n_samples, hipStream_t st)
 {
     const int P = g.ks / 2, KK = KS * KS;
     const int OH = MODE == 0 ? g.Ho : g.H + 2 * P, OW = MODE == 0 ? g.Wo : g.W + 2 * P;    // output pixel domain
     const int MOUT = MODE == 0 ? g.Cout : g.Cin, RED = MODE == 0 ? g.Cin : g.Cout;
     const int RED4 = (RED + 3) & ~3;
-    MfmaArgs A{xin, gin, g, mu, rho, key, sample_weights, out, dxp, dxp_sstride, 0, 0, 1};
+    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1};
 
     // Pick the largest tile that still gives the chip enough blocks: big tiles amortise the in-kernel weight sampling
     // (each sampled weight is reused by every pixel of the tile), small ones keep 256 CUs busy.  When the whole slab of a
@@ -464,25 +446,24 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
 }  // namespace
 
 // Returns -2 when the shape is not served by the MFMA path (caller falls back to the generic kernels).
-int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
-                         OutDesc out, int n_samples, hipStream_t st)
+int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st)
 {
     if (g.Cin > MFVI_MAX_C || (g.Cin & 3) || (g.w_off & 3)) return -2;      // Philox blocks must tile every weight row
     if ((long long)g.Cout * g.Ho * g.Wo >= (1LL << 31)) return -2;          // the epilogue uses 32-bit element offsets per sample
     GView none{};
-    if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
-    if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
-    if (g.ks == 1 && g.stride == 1) return launch_variant<1, 1, 0>(in, none, g, mu, rho, key, sample_weights, out, nullptr, 0, n_samples, st);
+    if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
+    if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
+    if (g.ks == 1 && g.stride == 1) return launch_variant<1, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
     return -2;
 }
 
-int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* mu, const float* rho, RngKey key, int sample_weights,
-                              float* dxp, long long dxp_sstride, int n_samples, hipStream_t st)
+int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w, long long wstride, float* dxp, long long dxp_sstride,
+                              int n_samples, hipStream_t st)
 {
     if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks == 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
     if ((long long)g.Cin * (g.H + 2) * (g.W + 2) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
     TView none{}; OutDesc od{};
-    if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
-    if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, mu, rho, key, sample_weights, od, dxp, dxp_sstride, n_samples, st);
+    if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
+    if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     return -2;
 }

@@ -265,7 +265,55 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// sample_weights: the reparameterisation draw of one pass, once per (layer, MC sample) instead of once per conv block:
+//   W_k[j] = mu[j] + softplus(rho[j]) * eps_k[j]       (BayTorch reparam_layers.py:26-37, modules/module.py:64-80)
+// eps_k from the counter RNG (domain EPS, stream 2*layer [+1 bias], sample k0+k, step); weights use the hardware-exp
+// softplus_fast, biases the libm-grade softplus_f — the same split the conv kernels used when they sampled in place.
+// grid: x = blocks of SAMPLE_QUADS quads over all layers of the table, y = sample.
+__global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* __restrict__ table, int n_entries,
+                                                             const float* __restrict__ mu, const float* __restrict__ rho,
+                                                             RngKey key, float* __restrict__ wsamp, long long wstride)
+{
+    int ei = 0;
+    while (ei + 1 < n_entries && table[ei + 1].first_block <= (int)blockIdx.x) ++ei;
+    const SampleEntry e = table[ei];
+    const int k = blockIdx.y;
+    const int item = ((int)blockIdx.x - e.first_block) * SAMPLE_QUADS + (int)threadIdx.x;
+    const int nq_w = e.n_w >> 2, nq_b = (e.n_b + 3) >> 2;
+    if (item >= nq_w + nq_b) return;
+    RngKey kw = key; kw.sample += (uint32_t)k;
+    float* __restrict__ o = wsamp + (long long)k * wstride;
+    float z[4];
+    if (item < nq_w) {
+        kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id);
+        spec_normal4(kw, (uint32_t)item, z);
+        const long long j = e.w_off + 4LL * item;
+        const float4 m = *reinterpret_cast<const float4*>(mu + j), r = *reinterpret_cast<const float4*>(rho + j);
+        float4 w;
+        w.x = __builtin_fmaf(softplus_fast(r.x), z[0], m.x); w.y = __builtin_fmaf(softplus_fast(r.y), z[1], m.y);
+        w.z = __builtin_fmaf(softplus_fast(r.z), z[2], m.z); w.w = __builtin_fmaf(softplus_fast(r.w), z[3], m.w);
+        *reinterpret_cast<float4*>(o + j) = w;
+    } else {
+        const int q = item - nq_w;
+        kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id + 1);
+        spec_normal4(kw, (uint32_t)q, z);
+        for (int l = 0; l < 4 && 4 * q + l < e.n_b; ++l) {
+            const long long j = e.b_off + 4 * q + l;
+            o[j] = mu[j] + softplus_f(rho[j]) * z[l];
+        }
+    }
+}
+
 }  // namespace
+
+int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const float* mu, const float* rho, RngKey key,
+                          int n_samples, float* wsamp, long long wstride, hipStream_t st)
+{
+    if (n_entries < 1 || n_blocks < 1) return 0;
+    hipLaunchKernelGGL(sample_weights_kernel, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride);
+    return (int)hipGetLastError();
+}
 
 int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
                          int sample_weights, int n_samples, float* dmu, float* drho, hipStream_t st)

@@ -50,6 +50,8 @@ struct mfvi_plan {
     long long float_base = 0;                  // byte offset of the float arena
     long long total_bytes = 0;
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
+    SampleEntry* samp_dev = nullptr; int n_samp = 0, samp_blocks = 0;    // layers whose weights are drawn once per pass
+    long long wsamp_off = -1;                  // floats: sampled weights [max_samples][n_vi]
     GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
     std::vector<GradFinEntry> fin_uploaded;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
@@ -162,6 +164,23 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         }
     const long long shared_off = take(shared_scratch);
     for (auto& o : p.ops) if (o.d.type == MFVI_OP_CONV && o.scratch_off < 0) o.scratch_off = shared_off;
+    // weights of the MFMA-served layers are sampled once per pass into [max_samples][n_vi]
+    std::vector<SampleEntry> samp;
+    for (auto& o : p.ops)
+        if (o.d.type == MFVI_OP_CONV && !(o.g.Cin & 3) && !(o.g.w_off & 3) && o.g.Cin <= MFVI_MAX_C && o.g.Cout <= MFVI_MAX_C) {
+            SampleEntry e{};
+            e.w_off = o.g.w_off; e.b_off = o.g.b_off; e.n_w = o.g.Cout * o.g.Cin * o.g.ks * o.g.ks; e.n_b = o.g.b_off >= 0 ? o.g.Cout : 0;
+            e.layer_id = o.g.layer_id; e.first_block = p.samp_blocks;
+            p.samp_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + SAMPLE_QUADS - 1) / SAMPLE_QUADS;
+            samp.push_back(e);
+        }
+    p.n_samp = (int)samp.size();
+    if (p.n_samp) {
+        p.wsamp_off = take(p.n_vi * p.max_samples);
+        hipError_t e = hipMalloc((void**)&p.samp_dev, sizeof(SampleEntry) * samp.size());
+        if (e == hipSuccess) e = hipMemcpy(p.samp_dev, samp.data(), sizeof(SampleEntry) * samp.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail("plan: sampling table setup failed: %s", hipGetErrorString(e));
+    }
     // partial-dW slabs: up to ~4M floats per layer, at least one pixel strip
     int n_conv = 0;
     for (auto& o : p.ops)
@@ -188,7 +207,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     return true;
 }
 
-enum { PASS_FWD = 0, PASS_BWD_WEIGHT = 1, PASS_BWD_DATA = 2, PASS_FINALIZE = 3, PASS_CONCAT_BWD = 4, PASS_GRAD_FINALIZE = 5 };
+enum { PASS_FWD = 0, PASS_BWD_WEIGHT = 1, PASS_BWD_DATA = 2, PASS_FINALIZE = 3, PASS_CONCAT_BWD = 4, PASS_GRAD_FINALIZE = 5, PASS_SAMPLE = 6 };
 
 struct ProfScope {
     mfvi_plan* p; hipStream_t st; bool on; hipEvent_t a, b; int op, pass;
@@ -208,6 +227,7 @@ struct Ctx {
     double* fstats() const { return (double*)ws; }
     double* bsums() const { return (double*)ws + p.stats_doubles; }
     float* farena() const { return (float*)(ws + p.float_base); }
+    float* wsamp() const { return p.wsamp_off >= 0 ? farena() + p.wsamp_off : nullptr; }
     TView view(int i, const float* out_ptr = nullptr) const
     {
         const TensorInfo& t = p.t[i]; TView v;
@@ -264,7 +284,7 @@ int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_
     if (!tensors || !ops || !plan) { set_error("plan_create: null argument"); return -1; }
     mfvi_plan* p = new mfvi_plan();
     p->input = input_tensor; p->output = output_tensor; p->n_vi = n_vi; p->n_bn = n_bn; p->max_samples = max_samples;
-    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); if (p->fin_dev) (void)hipFree(p->fin_dev); delete p; *plan = nullptr; return -1; }
+    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); if (p->fin_dev) (void)hipFree(p->fin_dev); if (p->samp_dev) (void)hipFree(p->samp_dev); delete p; *plan = nullptr; return -1; }
     *plan = p;
     return 0;
 }
@@ -276,6 +296,7 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     for (auto e : plan->free_events) (void)hipEventDestroy(e);
     if (plan->table_dev) (void)hipFree(plan->table_dev);
     if (plan->fin_dev) (void)hipFree(plan->fin_dev);
+    if (plan->samp_dev) (void)hipFree(plan->samp_dev);
     delete plan;
 }
 
@@ -293,6 +314,14 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
+    // MFMA-served layers: draw every weight once per (layer, sample); without sampling the kernels read mu (stride 0)
+    const bool presample = use_mfma() && sample_weights && plan->n_samp > 0;
+    if (presample) {
+        ProfScope ps(plan, -1, PASS_SAMPLE, st);
+        const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
+        if (rc) { set_error("forward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         const OpInfo& o = plan->ops[i];
         const TensorInfo& y = plan->t[o.d.out];
@@ -302,7 +331,7 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         int rc;
         ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV) {
-            rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st) : -2;
+            rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
@@ -326,6 +355,14 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
+    // the weights of this pass, re-drawn from the same counters (the buffer may have been overwritten since the forward)
+    const bool presample = use_mfma() && sample_weights && plan->n_samp > 0;
+    if (presample) {
+        ProfScope ps(plan, -1, PASS_SAMPLE, st);
+        const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
+        if (rc) { set_error("backward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
     std::vector<GradFinEntry> fin; int fin_blocks = 0;      // layers whose dW went to partial slabs in this pass
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) {
         const OpInfo& o = plan->ops[i];
@@ -350,7 +387,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                 const int P = o.g.ks / 2;
                 const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
                 { ProfScope ps(plan, i, PASS_BWD_DATA, st);
-                  rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st) : -2;
+                  rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, c.farena() + o.scratch_off, per, n_samples, st) : -2;
                   if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
                 const TensorInfo& x = plan->t[o.d.in0];
                 if (!rc && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
@@ -495,8 +532,8 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
         for (int which = 0; which < 3; ++which) {
             if (which == 1 && o.d.in0 == plan->input) continue;
             auto launch = [&]() {
-                if (which == 0) return launch_conv_fwd_mfma(xin, o.g, mu, rho, key, 1, od, n_samples, st);
-                if (which == 1) return launch_conv_bwd_data_mfma(gy, o.g, mu, rho, key, 1, c.farena() + o.scratch_off, per, n_samples, st);
+                if (which == 0) return launch_conv_fwd_mfma(xin, o.g, c.wsamp(), plan->n_vi, od, n_samples, st);
+                if (which == 1) return launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, c.farena() + o.scratch_off, per, n_samples, st);
                 return launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, nullptr, n_samples, st);
             };
             // candidate tilings: fwd / bwd-data (mf, th, T) = fragments x tile rows x tiles per block;
