@@ -32,7 +32,8 @@ struct WCfg {
     static constexpr int XPLANE = pitch2(IN_TH * IN_TW);
     static constexpr int ROW = CIB * KK;
     static constexpr int STAGE = 16 * GPLANE + CIB * XPLANE;
-    static constexpr int EPI = 16 * ROW + 16;
+    static constexpr int ROWP = ROW + 2;                                   // 4 * ROWP == 8 (mod 32): the 4 row groups of a wave spread over banks
+    static constexpr int EPI = 4 * 16 * ROWP + 64;                        // 4 wave regions of the cross-wave reduction + bias partials
     static constexpr int LDS_FLOATS = STAGE > EPI ? STAGE : EPI;
 };
 
@@ -247,24 +248,31 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         }
     }
 
-    // ---- sum the waves through LDS.  D layout: column n (ci) = lane & 15, row m (co) = (lane >> 4) * 4 + reg ----
+    // ---- sum the MFMA waves through LDS with plain stores (LDS float atomics cost ~700 cycles per wave instruction here):
+    //      wave w writes its fragments to region w & 3; with 8 MFMA waves, waves 4-7 then add theirs onto waves 0-3's (same
+    //      lane -> address map, so no conflicts); the 4 regions are summed on the way to global memory.
+    //      D layout: column n (ci) = lane & 15, row m (co) = (lane >> 4) * 4 + reg ----
+    constexpr int ROWP = Cfg::ROWP;
     __syncthreads();
-    float* s_dw = lds;                  // [16][ROW]   dW tile, element (co, ci*KK + tap)
-    float* s_db = lds + 16 * ROW;       // [16]
-    for (int i = t; i < 16 * ROW; i += NT) s_dw[i] = 0.f;
-    if (t < 16) s_db[t] = 0.f;
-    __syncthreads();
-    if (!producer) {
+    float* s_ep = lds;                      // [4][16][ROWP]   dW fragments per wave region, element (co, ci*KK + tap)
+    float* s_db = lds + 4 * 16 * ROWP;      // [4][16]         bias-gradient partials
+    const int rw = wv & 3;
+    auto put = [&](bool add) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < KK; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&s_dw[(l4 * 4 + r) * ROW + (b * 16 + l15) * KK + q], acc[b][q][r]);
+                for (int r = 0; r < 4; ++r) {
+                    float* d = &s_ep[(rw * 16 + l4 * 4 + r) * ROWP + (b * 16 + l15) * KK + q];
+                    *d = add ? *d + acc[b][q][r] : acc[b][q][r];
+                }
         if (do_bias && l15 == 0)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&s_db[l4 * 4 + r], accb[r]);
-    }
+            for (int r = 0; r < 4; ++r) { float* d = &s_db[rw * 16 + l4 * 4 + r]; *d = add ? *d + accb[r] : accb[r]; }
+    };
+    if (!producer && wv < 4) put(false);
+    if (NW == 8) { __syncthreads(); if (wv >= 4) put(true); }
     __syncthreads();
 
     // ---- this block's partial sums -> its slab (contiguous rows; every (strip, sample) slab is covered exactly once) ----
@@ -272,9 +280,12 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     float* __restrict__ o = part + ((long long)bx * nz + k) * part_stride;
     for (int idx = t; idx < 16 * len; idx += NT) {
         const int r = idx / len, rel = idx - r * len, co = co0 + r;
-        if (co < Cout) o[((long long)co * Cin + ci0) * KK + rel] = s_dw[r * ROW + rel];
+        if (co < Cout) {
+            const float* e = s_ep + r * ROWP + rel;
+            o[((long long)co * Cin + ci0) * KK + rel] = (e[0] + e[16 * ROWP]) + (e[2 * 16 * ROWP] + e[3 * 16 * ROWP]);
+        }
     }
-    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = s_db[t];
+    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = (s_db[t] + s_db[16 + t]) + (s_db[32 + t] + s_db[48 + t]);
 }
 
 int env_tune_w()
