@@ -164,6 +164,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             constexpr int NPX = (IN_TH * IN_TW + 63) / 64;                // passes of 64 lanes over the input tile
             constexpr int NPG = PIX / 64;                                 // passes over the output-pixel tile
             const int pw = wv - NW;
+            __builtin_amdgcn_s_setprio(2);                                // younger half of the workgroup: do not starve behind the MFMA stream
             float pxr[CPW][NPX], pgr[4][NPG], pyr[4][NPG];
             int pxo[NPX], pgo[NPG];
             ChanFwd cx[CPW]; ChanBwd cgk[4];

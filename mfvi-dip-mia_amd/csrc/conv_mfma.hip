@@ -27,6 +27,10 @@
 
 namespace {
 
+#ifndef PRODUCER_PRIO
+#define PRODUCER_PRIO 2
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int pitch16(int n) { return ((n + 15) / 32) * 32 + 16; }      // smallest p >= n with p % 32 == 16
@@ -155,6 +159,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
 
     if (producer) {
         // ======================= producer waves =======================
+        // The second-dispatched half of a 512-thread workgroup loses VALU arbitration to the older (consumer) wave of its SIMD
+        // (priority, then age): raise the producers once so their short VALU bursts are not starved by the MFMA stream.
+        __builtin_amdgcn_s_setprio(PRODUCER_PRIO);
         const float* __restrict__ xsrc = MODE == 0 ? A.xin.data + (long long)k * A.xin.sstride : A.gin.ga + (long long)k * A.gin.gstride;
         const float* __restrict__ ysrc = (MODE == 1 && A.gin.y) ? A.gin.y + (long long)k * A.gin.ystride : nullptr;
         const int xact = A.xin.act; const float xslope = A.xin.slope;

@@ -25,7 +25,7 @@ rep('''        lds_barrier();                                    // (A) chunk 0 
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 store(nc, s_x[(it + 1) & 1]);
-                if (!WS) { const int cc = min(CC, RED - nc); sample_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
+                if (!WS) { const int cc = min(CC, RED - nc); load_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
                 if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
             }
             lds_barrier();
@@ -39,7 +39,7 @@ rep('''        lds_barrier();                                    // (A) chunk 0 
                 TICK(6)
                 store(nc, s_x[(it + 1) & 1]);
                 TICK(3)
-                if (!WS) { const int cc = min(CC, RED - nc); sample_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
+                if (!WS) { const int cc = min(CC, RED - nc); load_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
                 TICK(4)
                 if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
                 TICK(1)
@@ -74,8 +74,8 @@ rep('''                              s_red[0][q][which] + s_red[1][q][which] + s
     TICK(7)
     if (A.prof && bx == 1 && by == 0 && k == 3 && (threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) A.prof[(threadIdx.x >> 6) * 8 + i] = T[i];
 }''')
-rep("    MfmaArgs A{xin, gin, g, mu, rho, key, sample_weights, out, dxp, dxp_sstride, 0, 0, 1};",
-    "    static long long* prof = [] { long long* p = nullptr; if (getenv(\"MFVI_PROF\")) { (void)hipMalloc((void**)&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();\n    MfmaArgs A{xin, gin, g, mu, rho, key, sample_weights, out, dxp, dxp_sstride, 0, 0, 1, 0, 0, 0, prof};")
+rep("    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1};",
+    "    static long long* prof = [] { long long* p = nullptr; if (getenv(\"MFVI_PROF\")) { (void)hipMalloc((void**)&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();\n    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1, 0, 0, 0, prof};")
 rep("        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO_MF",
     "        if (prof) { long long h[64]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost); fprintf(stderr, \"MODE %d KS %d mf %d th %d T %d tiles %d my %d chunks/tile %d\\n\", MODE, KS, MF_, TH_, A.tiles_per_block, A.n_tiles, my, (RED + 7) / 8); for (int w = 0; w < 8; ++w) { fprintf(stderr, \"wave %d:\", w); for (int i = 0; i < 8; ++i) fprintf(stderr, \" %lld\", h[w * 8 + i]); fprintf(stderr, \"\\n\"); } } \\\n        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO_MF")
 rep("#include <cstdlib>", "#include <cstdlib>\n#include <cstdio>")
