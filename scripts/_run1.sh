@@ -1,7 +1,6 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest.log 2>&1 || { tail -40 gpurun_out/pytest.log; exit 1; }
-tail -3 gpurun_out/pytest.log
-timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-all > gpurun_out/bench_at.log 2>&1
-tail -1 gpurun_out/bench_at.log | cut -c1-300
-grep -v "^{" gpurun_out/bench_at.log | head -30
+for d in 0 4; do
+MFVI_DBG=$d MFVI_PROF=1 MFVI_AUTOTUNE=0 MFVI_TUNE=1,16,1 timeout -k 10 120 python scripts/bench_layer.py 132 128 3 1 32 32 16 1 > gpurun_out/prof1.log 2>&1
+echo "dbg $d"; grep -A8 "^MODE 1 KS 3" gpurun_out/prof1.log | tail -9; grep "bwd_data" gpurun_out/prof1.log | tail -1
+done
