@@ -58,9 +58,13 @@ struct MfmaArgs {
     OutDesc out; float* dxp; long long dxp_sstride;
     int tiles_x, n_tiles, tiles_per_block;
     int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
+    int ow, rt, wpitch, nwin;              // FLAT tiles: output-domain width, rows per tile, window pitch, window positions
 };
 
-template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS>
+// FLAT: for narrow output domains (<= ~66 wide) a tile is `rt` FULL rows of the domain, its TH*32 pixels dealt to the MFMA
+// fragments in row-major order, instead of a TH x 32 rectangle: a 34-wide padded-gradient domain then fills 99% of the
+// fragments (2 x 32-pixel tile columns fill 53%).  The staged window keeps the same LDS plane with a run-time pitch.
+template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT>
 __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1))) void conv_mfma_kernel(MfmaArgs A)
 {
     using Cfg = MCfg<KS, STRIDE, MF, TH>;
@@ -173,14 +177,15 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
         constexpr int NPX = (NPOSW + 63) / 64;
         static_assert(PITCH == IN_TW, "window rows are stored back to back");
         const int pw = wv;
+        const int nwin = FLAT ? A.nwin : NPOSW;                  // positions actually staged (FLAT: rows x run-time pitch <= NPOSW)
         int goff[NPX];                                           // global offset of position lane + 64*j; -1 = stage a zero
         auto set_tile = [&](int tile) {
-            const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+            const int px0 = FLAT ? 0 : (tile % A.tiles_x) * TW, py0 = FLAT ? tile * A.rt : (tile / A.tiles_x) * TH;
             const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
             const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (KS - 1);
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
-                const int p = min(lane + 64 * j, NPOSW - 1), iy = p / IN_TW, ix = p - iy * IN_TW;
+                const int p = min(lane + 64 * j, nwin - 1), iy = FLAT ? p / A.wpitch : p / IN_TW, ix = p - iy * (FLAT ? A.wpitch : IN_TW);
                 int gy = sy0 + iy, gx = sx0 + ix;
                 if (MODE == 0) {
                     gy = reflect_idx(gy, H); gx = reflect_idx(gx, W);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                     if (MODE == 0) v = apply_fwd(kf, xr[i][j], xact, xslope);
                     else v = ysrc ? apply_bwd(kb, xr[i][j], yr[i][j]) : xr[i][j];
                     if (!live || (MODE == 1 && goff[j] < 0)) v = 0.f;
-                    if (64 * (j + 1) <= NPOSW || p < NPOSW) dst[cl * PLANE + p] = v;
+                    if ((!FLAT && 64 * (j + 1) <= NPOSW) || p < nwin) dst[cl * PLANE + p] = v;
                 }
             }
         };
@@ -252,11 +257,20 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
         if (MODE == 0 && A.out.stats != nullptr) __syncthreads();        // (Z) consumers publish their BN partial sums
     } else {
         // ======================= consumer waves =======================
-        int boff[NF];
+        int boff[FLAT ? 1 : NF], boffk[FLAT ? NF : 1][FLAT ? KS : 1], frc[FLAT ? NF : 1];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
-            boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE;
+            if (FLAT) {      // pixel q of the tile (row-major over rt full rows of the domain) -> (r, c); fixed for the whole kernel
+                const int q = (wv * NF + f) * 16 + l15, r = q / A.ow, c = q - r * A.ow;
+                const bool ok = r < A.rt;
+                frc[f] = ok ? (r << 16 | c) : -1;
+                const int base = l4 * PLANE + (ok ? r * STRIDE * A.wpitch + c * STRIDE : 0);
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) boffk[f][ky] = base + ky * A.wpitch;
+            } else {
+                const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
+                boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE;
+            }
         }
         const int aoff = l4 * CTP + l15;
         const int wtap = REDP * CTP;
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
 #pragma unroll
                     for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + st_ * 4 * CTP + i * 16];
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) bb[f] = sx[st_ * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                    for (int f = 0; f < NF; ++f) bb[f] = FLAT ? sx[st_ * 4 * PLANE + boffk[f][ky] + kx] : sx[st_ * 4 * PLANE + boff[f] + ky * PITCH + kx];
                 };
                 load(0, a[0], b[0]);
 #pragma unroll
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             if (ci == n_chunks - 1) {
                 // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg.
                 // 32-bit element offsets from a wave-uniform base keep the address math out of the VGPR budget.
-                const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+                const int px0 = FLAT ? 0 : (tile % A.tiles_x) * TW, py0 = FLAT ? tile * A.rt : (tile / A.tiles_x) * TH;
                 if (MODE == 0) {
                     const int HWo = g.Ho * g.Wo;
                     float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HWo;
@@ -319,8 +333,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                     for (int i = 0; i < MF; ++i) {
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
-                            const int oy = py0 + wv * (TH / 4) + (f >> 1), ox = px0 + (f & 1) * 16 + l15;
-                            if (oy < g.Ho && ox < g.Wo) {
+                            const int oy = FLAT ? py0 + (frc[f] >> 16) : py0 + wv * (TH / 4) + (f >> 1);
+                            const int ox = FLAT ? (frc[f] & 0xffff) : px0 + (f & 1) * 16 + l15;
+                            if ((!FLAT || frc[f] >= 0) && oy < g.Ho && ox < g.Wo) {
                                 const int pofs = rowbase + oy * g.Wo + ox;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -353,8 +368,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
-                            const int pr = py0 + wv * (TH / 4) + (f >> 1), pc = px0 + (f & 1) * 16 + l15;
-                            if (pr < Hp && pc < Wp) {
+                            const int pr = FLAT ? py0 + (frc[f] >> 16) : py0 + wv * (TH / 4) + (f >> 1);
+                            const int pc = FLAT ? (frc[f] & 0xffff) : px0 + (f & 1) * 16 + l15;
+                            if ((!FLAT || frc[f] >= 0) && pr < Hp && pc < Wp) {
                                 const int pofs = rowbase + pr * Wp + pc;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -409,11 +425,21 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && cost(order[j]) < cost(order[j - 1]); --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
     const long long want = 768;
     int forced_T = 0;
-#define GO(MF_, TH_)                                                                                                       \
+#define GO_(MF_, TH_, FL_)                                                                                                 \
     {                                                                                                                      \
         using Cfg = MCfg<KS, STRIDE, MF_, TH_>;                                                                            \
         A.tiles_x = (OW + 31) / 32;                                                                                        \
         A.n_tiles = A.tiles_x * ((OH + TH_ - 1) / TH_);                                                                    \
+        if (FL_) {                                                                                                         \
+            A.ow = OW; A.wpitch = (OW - 1) * STRIDE + KS;                                                                  \
+            int rt = (TH_ * 32) / OW;                                                                                      \
+            const int cap = (Cfg::IN_TH * Cfg::IN_TW) / A.wpitch;            /* window rows that fit the LDS plane */      \
+            if ((rt - 1) * STRIDE + KS > cap) rt = (cap - KS) / STRIDE + 1;                                                \
+            if (rt > OH) rt = OH;                                                                                          \
+            if (rt < 1 || OW > 0xffff) return -3;                                                                          \
+            A.rt = rt; A.nwin = ((rt - 1) * STRIDE + KS) * A.wpitch;                                                       \
+            A.n_tiles = (OH + rt - 1) / rt;                                                                                \
+        }                                                                                                                  \
         const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
         const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP, ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * Cfg::CTP; \
         const long long nb = (long long)A.n_tiles * my * n_samples;                                                        \
@@ -422,20 +448,30 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         if (T >= 2 && ws_bytes <= 40 * 1024) {                                                                             \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
         } else {                                                                                                           \
             if (forced_T > 1) return -3;                                                                                   \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
-            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }
+#define GO(MF_, TH_) GO_(MF_, TH_, false)
 #define GO_MF(mf_, TH_) { if ((mf_) == 1) GO(1, TH_) if ((mf_) == 2) GO(2, TH_) if ((mf_) == 3) GO(3, TH_) }
+#define GO_MF_FLAT(mf_, TH_) { if ((mf_) == 1) GO_(1, TH_, true) if ((mf_) == 2) GO_(2, TH_, true) if ((mf_) == 3) GO_(3, TH_, true) }
     const int forced = g.tune[MODE] ? g.tune[MODE] : env_tune();
     if (forced) {              // explicit tiling (mf | th << 8 | T << 16); -3 = not a valid tiling for this shape
         const int mf = forced & 255, th = (forced >> 8) & 255;
         forced_T = (forced >> 16) & 255;
+        if (th & 128) {        // FLAT tiles: 3x3 stride-1 kernels on domains up to 130 wide
+            if constexpr (KS == 3 && STRIDE == 1) {
+                if (OW > 130) return -3;
+                if ((th & 127) == 16) { if (OH * OW >= 256) GO_MF_FLAT(mf, 16) return -3; }
+                if ((th & 127) == 8) { GO_MF_FLAT(mf, 8) if (mf == 4) GO_(4, 8, true) }
+            }
+            return -3;
+        }
         if (th == 16) { if constexpr (STRIDE == 1) { if (OH >= 16) GO_MF(mf, 16) } return -3; }
         if (th == 8) { GO_MF(mf, 8) if (mf == 4) GO(4, 8) }
         return -3;
@@ -446,8 +482,10 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     }
     for (int i = 0; i < 4; ++i) if (blocks(order[i], 8) >= want) { GO_MF(order[i], 8) if (order[i] == 4) GO(4, 8) }
     GO(1, 8)
+#undef GO_MF_FLAT
 #undef GO_MF
 #undef GO
+#undef GO_
 }
 
 }  // namespace
