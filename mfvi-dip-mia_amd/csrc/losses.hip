@@ -231,10 +231,23 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
         const float* __restrict__ P = part_base + e.part_off + col;
         for (int k = wv; k < n_samples; k += 4) {
             float sk[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int sidx = 0; sidx < e.strips; ++sidx) {
-                const float* __restrict__ q = P + ((long long)sidx * n_samples + k) * e.stride;
-                if (is_w) { const float4 v = *reinterpret_cast<const float4*>(q); sk[0] += v.x; sk[1] += v.y; sk[2] += v.z; sk[3] += v.w; }
-                else for (int l = 0; l < nv; ++l) sk[l] += q[l];
+            const float* __restrict__ q0 = P + (long long)k * e.stride;
+            const long long sstep = (long long)n_samples * e.stride;          // next pixel strip of the same sample
+            if (is_w) {
+                int sidx = 0;
+                for (; sidx + 4 <= e.strips; sidx += 4) {                     // 4 independent loads in flight
+                    const float4 v0 = *reinterpret_cast<const float4*>(q0 + (sidx + 0) * sstep), v1 = *reinterpret_cast<const float4*>(q0 + (sidx + 1) * sstep);
+                    const float4 v2 = *reinterpret_cast<const float4*>(q0 + (sidx + 2) * sstep), v3 = *reinterpret_cast<const float4*>(q0 + (sidx + 3) * sstep);
+                    sk[0] += (v0.x + v1.x) + (v2.x + v3.x); sk[1] += (v0.y + v1.y) + (v2.y + v3.y);
+                    sk[2] += (v0.z + v1.z) + (v2.z + v3.z); sk[3] += (v0.w + v1.w) + (v2.w + v3.w);
+                }
+                for (; sidx < e.strips; ++sidx) {
+                    const float4 v = *reinterpret_cast<const float4*>(q0 + sidx * sstep);
+                    sk[0] += v.x; sk[1] += v.y; sk[2] += v.z; sk[3] += v.w;
+                }
+            } else {
+                for (int sidx = 0; sidx < e.strips; ++sidx)
+                    for (int l = 0; l < nv; ++l) sk[l] += q0[sidx * sstep + l];
             }
 #pragma unroll
             for (int l = 0; l < 4; ++l) am[l] += sk[l];

@@ -531,10 +531,11 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
         const TView xin = c.view(o.d.in0);
         for (int which = 0; which < 3; ++which) {
             if (which == 1 && o.d.in0 == plan->input) continue;
+            int strips_used = 0;
             auto launch = [&]() {
                 if (which == 0) return launch_conv_fwd_mfma(xin, o.g, c.wsamp(), plan->n_vi, od, n_samples, st);
                 if (which == 1) return launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, c.farena() + o.scratch_off, per, n_samples, st);
-                return launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, nullptr, n_samples, st);
+                return launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips_used, n_samples, st);
             };
             // candidate tilings: fwd / bwd-data (mf, th, T) = fragments x tile rows x tiles per block;
             //                    bwd-weight (nb, waves, target/256) = input tiles per block x waves x block-count target
@@ -555,6 +556,8 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
                 e = hipEventSynchronize(eb);
                 if (e == hipSuccess) e = hipEventElapsedTime(&ms, ea, eb);
                 if (rc || e != hipSuccess) { set_error("autotune: op %d timing failed: %s", (int)i, hipGetErrorString(rc ? (hipError_t)rc : e)); rc = rc ? rc : (int)e; goto done; }
+                // backward-weight: every extra pixel strip is one more slab grad_finalize has to read (~2 TB/s there)
+                if (which == 2) ms += reps * (float)((double)strips_used * n_samples * o.part_stride * 4.0 / 2.0e12 * 1e3);
                 if (ms < best_ms) { best_ms = ms; best = cand; }
             }
             o.g.tune[which] = best;
