@@ -127,7 +127,7 @@ def main():
             cls[kind] = cls.get(kind, 0.0) + ms
         for kind, ms in sorted(cls.items(), key=lambda kv: -kv[1]):
             sys.stderr.write("  %-22s %8.3f ms %5.1f%%\n" % (kind, ms, 100 * ms / tot))
-        for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:24]:
+        for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:(200 if os.environ.get('MFVI_PROFILE_FULL') else 24)]:
             c = conv_cost(eng.prog, op, eng.chunk) if op >= 0 else None
             sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else ("all layers" if op < 0 else "concat_up")))
         sys.stderr.write("sum of kernel times in one iteration: %.3f ms\n" % tot)
@@ -137,6 +137,20 @@ def main():
     for i in range(5):
         eng.forward_only(step=1000 + i)
     torch.cuda.synchronize(); fwd_only = 5 * eng.K_local * world / (time.perf_counter() - t0)
+
+    # ELBO iterations WITH the reference loop's per-iteration bookkeeping (EMA, clips, ring buffers, 2 MSE + 3 PSNR + 3 SSIM:
+    # bayesian_optimization.py:1374-1406) — SURVEY 8(d)(ii) asks for the rate with and without it (extra information, untimed region)
+    with_book = None
+    if world == 1:
+        from mfvi_dip_mia_amd.runner import _Book
+        gt = O.phantom(S, S, DEN["seed"])
+        book = _Book(eng, 16, gt, O.noisy(gt, DEN["p_sigma"], DEN["seed"]))
+        for i in range(3):
+            eng.step(); book.iteration(eng, i, eng.chunk)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(3, 13):
+            eng.step(); book.iteration(eng, i, eng.chunk)
+        torch.cuda.synchronize(); with_book = 10 / (time.perf_counter() - t0)
 
     # ---- timed region: exactly --steps iterations, only the dominant kernel carries events ----
     eng.plan.profile(2, dom_op, dom_pass)
@@ -183,7 +197,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "mfvi_den.json hyper-parameters, %dx%d grayscale, K=%d MC samples per GPU, 26-layer skip net, single fused-HIP path" % (S, S, K),
                        "mc_samples_per_iteration": eng.K_local * world, "parallelism": "mc-sample sharding x%d, 1 all-reduce/iter" % world},
-            "elbo_iters_per_sec": args.steps / dt, "fwd_only_mc_passes_per_sec": fwd_only,
+            "elbo_iters_per_sec": args.steps / dt, "elbo_iters_per_sec_with_bookkeeping": with_book, "fwd_only_mc_passes_per_sec": fwd_only,
             "final_loss": loss, "final_nll": nll, "final_kl": kl,
             "roofline": roof,
         }

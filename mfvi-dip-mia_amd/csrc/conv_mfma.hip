@@ -32,6 +32,7 @@ namespace {
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f2a __attribute__((ext_vector_type(2)));
 
 constexpr int pitch16(int n) { return ((n + 15) / 32) * 32 + 16; }      // smallest p >= n with p % 32 == 16
 
@@ -44,12 +45,18 @@ struct MCfg {
     static constexpr int KK = KS * KS;
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
     static constexpr int IN_TW = (TW - 1) * STRIDE + KS;
-    static constexpr int PITCH = IN_TW;
+    // Rectangular tiles stage the window as ALIGNED float4 columns: the LDS row starts 4 columns left of the tile when there is a
+    // halo (the tile starts at a multiple of 32 columns, images are a multiple of 4 wide), so a row is WV floats and the first
+    // column a tap needs sits at XOFF (+1 less for backward-data, whose halo is KS-1 instead of KS/2).
+    static constexpr int HALO4 = KS > 1 ? 4 : 0;
+    static constexpr int WV = ((HALO4 ? 3 : 0) + IN_TW + 3) / 4 * 4;   // 40 (3x3), 68 (3x3 stride 2), 32 (1x1)
+    static constexpr int PITCH = WV;
     static constexpr int PLANE = pitch16(IN_TH * PITCH);           // == 16 (mod 32)
     static constexpr int CTP = pitch16(CT);                        // == 16 (mod 32)
     static constexpr int X_FLOATS = CC * PLANE;
 };
 
+static_assert(MCfg<3, 1, 1, 16>::WV == 40 && MCfg<3, 2, 1, 8>::WV == 68 && MCfg<1, 1, 1, 16>::WV == 32 && MCfg<3, 1, 1, 16>::PLANE == 720, "window");
 static_assert(pitch16(16) == 16 && pitch16(32) == 48 && pitch16(64) == 80 && pitch16(340) % 32 == 16, "pitch16");
 
 struct MfmaArgs {
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
     // chunk (global loads -> deferred BN/LeakyReLU or BN-backward -> LDS) and sample the next weight chunk into the
     // other half of a double buffer.  One barrier per chunk; VALU/VMEM work hides under the matrix pipe.
     extern __shared__ __align__(16) float s_w[];          // WS: [KK][REDP][CTP]; else 2 x [KK][CC][CTP]
-    __shared__ float s_x[2][Cfg::X_FLOATS];
+    __shared__ __align__(16) float s_x[2][Cfg::X_FLOATS];
     __shared__ ChanFwd s_ch[MODE == 0 ? MFVI_MAX_C : 1];
     __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
@@ -173,19 +180,18 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
         // tile window: the channel is wave-uniform (its BN constants are read once per chunk, not per element) and the LDS
         // address of position p is p itself (PITCH == IN_TW), so an element costs a transform and one ds_write.
         constexpr int CPW = CC / 4;
-        constexpr int NPOSW = IN_TH * IN_TW;                     // positions of the staged window
+        constexpr int NPOSW = IN_TH * PITCH;                     // capacity of one LDS channel plane
         constexpr int NPX = (NPOSW + 63) / 64;
-        static_assert(PITCH == IN_TW, "window rows are stored back to back");
         const int pw = wv;
-        const int nwin = FLAT ? A.nwin : NPOSW;                  // positions actually staged (FLAT: rows x run-time pitch <= NPOSW)
-        int goff[NPX];                                           // global offset of position lane + 64*j; -1 = stage a zero
-        auto set_tile = [&](int tile) {
-            const int px0 = FLAT ? 0 : (tile % A.tiles_x) * TW, py0 = FLAT ? tile * A.rt : (tile / A.tiles_x) * TH;
+        const int nwin = A.nwin;                                 // positions actually staged (rows x run-time pitch <= NPOSW)
+        int goff[FLAT ? NPX : 1];                                           // global offset of position lane + 64*j; -1 = stage a zero
+        auto set_tile_s = [&](int tile) {
+            const int px0 = 0, py0 = tile * A.rt;
             const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
             const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (KS - 1);
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
-                const int p = min(lane + 64 * j, nwin - 1), iy = FLAT ? p / A.wpitch : p / IN_TW, ix = p - iy * (FLAT ? A.wpitch : IN_TW);
+                const int p = min(lane + 64 * j, nwin - 1), iy = p / A.wpitch, ix = p - iy * A.wpitch;
                 int gy = sy0 + iy, gx = sx0 + ix;
                 if (MODE == 0) {
                     gy = reflect_idx(gy, H); gx = reflect_idx(gx, W);
@@ -200,9 +206,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                 }
             }
         };
-        float xr[CPW][NPX], yr[MODE == 1 ? CPW : 1][MODE == 1 ? NPX : 1];
+        float xr[FLAT ? CPW : 1][FLAT ? NPX : 1], yr[(FLAT && MODE == 1) ? CPW : 1][(FLAT && MODE == 1) ? NPX : 1];
         // Branch-free: every load uses a valid (clamped) address; invalid positions / channels are zeroed at the LDS store.
-        auto prefetch = [&](int c0) {
+        auto prefetch_s = [&](int c0) {
 #pragma unroll
             for (int i = 0; i < CPW; ++i) {
                 const long long cb = (long long)min(c0 + pw * CPW + i, RED - 1) * SHW;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                 }
             }
         };
-        auto store = [&](int c0, float* __restrict__ dst) {      // registers -> LDS with the deferred transform
+        auto store_s = [&](int c0, float* __restrict__ dst) {      // registers -> LDS with the deferred transform
             const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
 #pragma unroll
             for (int i = 0; i < CPW; ++i) {
@@ -231,10 +237,98 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                     if (MODE == 0) v = apply_fwd(kf, xr[i][j], xact, xslope);
                     else v = ysrc ? apply_bwd(kb, xr[i][j], yr[i][j]) : xr[i][j];
                     if (!live || (MODE == 1 && goff[j] < 0)) v = 0.f;
-                    if ((!FLAT && 64 * (j + 1) <= NPOSW) || p < nwin) dst[cl * PLANE + p] = v;
+                    if (p < nwin) dst[cl * PLANE + p] = v;
                 }
             }
         };
+        // ---- rectangular tiles: aligned float4 staging ----
+        // Item q = lane + 64*j of a channel is float4 column v of window row iy (NV4 columns per row).  A float4 is wholly
+        // inside or wholly outside the image (tile origins and image widths are multiples of 4); reflection only ever needs
+        // one element of an outside float4 (column -1 <- x[1], column W <- x[W-2]), taken from the neighbouring inside one.
+        constexpr int NV4 = PITCH / 4, NITEM = IN_TH * NV4, NV = (NITEM + 63) / 64;
+        int voff[FLAT ? 1 : NV];          // global element offset of the float4 to load (always valid), with flags in the low 2 bits:
+                                          // 1 = left-reflected (keep .y as column 3), 2 = right-reflected (.z as column 0), 3 = stage zeros
+        float4 xv[FLAT ? 1 : CPW][FLAT ? 1 : NV], yv[(!FLAT && MODE == 1) ? CPW : 1][(!FLAT && MODE == 1) ? NV : 1];
+        auto set_tile_v = [&](int tile) {
+            const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+            const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
+            const int ax0 = (MODE == 0 ? px0 * STRIDE : px0) - Cfg::HALO4;            // aligned first column of the LDS row
+            const bool stuffed = MODE == 1 && g.stride == 2;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int q = min(lane + 64 * j, NITEM - 1), iy = q / NV4, v = q - iy * NV4;
+                int gy = sy0 + iy, gx = ax0 + 4 * v, flag = 0;
+                if (MODE == 0) {
+                    gy = reflect_idx(gy, H); gy = min(max(gy, 0), H - 1);               // tile overhang: masked at the store
+                    if (gx < 0) { flag = 1; gx = 0; } else if (gx >= W) { flag = gx == W ? 2 : 3; gx = W - 4; }
+                    voff[j] = (gy * W + gx) | flag;                                     // gx % 4 == 0, W % 4 == 0: low bits are free
+                } else if (stuffed) {
+                    // zero-stuffed gradient G[r][c] = dy[r/2][c/2] (r, c even): window columns gx..gx+3 <- (s[gx/2], 0, s[gx/2+1], 0)
+                    const bool ok = gy >= 0 && !(gy & 1) && (gy >> 1) < SH && gx >= 0 && (gx >> 1) < SW;      // SW even: the pair is inside together
+                    voff[j] = ok ? (((gy >> 1) * SW + (gx >> 1)) << 2) : 3;            // 8-byte aligned pair; offset kept in bits 2..
+                } else {
+                    const bool ok = gy >= 0 && gy < SH && gx >= 0 && gx < SW;
+                    voff[j] = ok ? (gy * SW + gx) : 3;
+                }
+            }
+        };
+        auto prefetch_v = [&](int c0) {
+            const bool stuffed = MODE == 1 && g.stride == 2;
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                const long long cb = (long long)min(c0 + pw * CPW + i, RED - 1) * SHW;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    if (stuffed) {
+                        const long long off = cb + (voff[j] >> 2);
+                        const f2a a = *reinterpret_cast<const f2a*>(xsrc + off);
+                        xv[i][j] = make_float4(a.x, 0.f, a.y, 0.f);
+                        if (MODE == 1) { if (ysrc) { const f2a b = *reinterpret_cast<const f2a*>(ysrc + off); yv[i][j] = make_float4(b.x, 0.f, b.y, 0.f); } else yv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    } else {
+                        const long long off = cb + (voff[j] & ~3);
+                        xv[i][j] = *reinterpret_cast<const float4*>(xsrc + off);
+                        if (MODE == 1) yv[i][j] = ysrc ? *reinterpret_cast<const float4*>(ysrc + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        };
+        auto store_v = [&](int c0, float* __restrict__ dst) {    // registers -> LDS with the deferred transform
+            const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
+            const bool stuffed = MODE == 1 && g.stride == 2;
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                const int cl = pw * CPW + i;
+                if (cl >= cc4) continue;                          // wave-uniform: channel beyond the padded chunk
+                const bool live = cl < cc;
+                const int ch = min(c0 + cl, RED - 1);
+                ChanFwd kf; ChanBwd kb;
+                if (MODE == 0) kf = s_ch[ch]; else kb = s_chb[ch];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int q = lane + 64 * j;
+                    const int flag = voff[j] & 3;
+                    float e[4] = {xv[i][j].x, xv[i][j].y, xv[i][j].z, xv[i][j].w};
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) e[l] = apply_fwd(kf, e[l], xact, xslope);
+                        if (flag == 1) { e[3] = e[1]; }                      // column -1 <- x[1]   (columns -4..-2 are never read)
+                        else if (flag == 2) { e[0] = e[2]; }                 // column W  <- x[W-2] (columns W+1.. only feed masked outputs)
+                    } else {
+                        if (ysrc) {
+                            const float yy[4] = {yv[i][j].x, yv[i][j].y, yv[i][j].z, yv[i][j].w};
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) e[l] = apply_bwd(kb, e[l], yy[l]);
+                        }
+                        if (stuffed) { e[1] = 0.f; e[3] = 0.f; }
+                    }
+                    if (!live || (MODE == 1 && (stuffed ? voff[j] == 3 : flag == 3))) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+                    if (64 * (j + 1) <= NITEM || q < NITEM) *reinterpret_cast<float4*>(dst + cl * PLANE + 4 * q) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+        };
+        auto set_tile = [&](int tile) { if constexpr (FLAT) set_tile_s(tile); else set_tile_v(tile); };
+        auto prefetch = [&](int c0) { if constexpr (FLAT) prefetch_s(c0); else prefetch_v(c0); };
+        auto store = [&](int c0, float* __restrict__ dst) { if constexpr (FLAT) store_s(c0, dst); else store_v(c0, dst); };
         auto chunk_of = [&](int it, int& tile, int& c0) { tile = tile_begin + it / n_chunks; c0 = (it % n_chunks) * CC; };
 
         int ptile, pc0;
@@ -269,7 +363,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                 for (int ky = 0; ky < KS; ++ky) boffk[f][ky] = base + ky * A.wpitch;
             } else {
                 const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
-                boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE;
+                boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? (MODE == 0 ? 3 : 2) : 0);
             }
         }
         const int aoff = l4 * CTP + l15;
@@ -433,7 +527,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         if (FL_) {                                                                                                         \
             A.ow = OW; A.wpitch = (OW - 1) * STRIDE + KS;                                                                  \
             int rt = (TH_ * 32) / OW;                                                                                      \
-            const int cap = (Cfg::IN_TH * Cfg::IN_TW) / A.wpitch;            /* window rows that fit the LDS plane */      \
+            const int cap = (Cfg::IN_TH * Cfg::PITCH) / A.wpitch;            /* window rows that fit the LDS plane */      \
             if ((rt - 1) * STRIDE + KS > cap) rt = (cap - KS) / STRIDE + 1;                                                \
             if (rt > OH) rt = OH;                                                                                          \
             if (rt < 1 || OW > 0xffff) return -3;                                                                          \
@@ -495,6 +589,8 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
 {
     if (g.Cin > MFVI_MAX_C || (g.Cin & 3) || (g.w_off & 3)) return -2;      // Philox blocks must tile every weight row
     if ((long long)g.Cout * g.Ho * g.Wo >= (1LL << 31)) return -2;          // the epilogue uses 32-bit element offsets per sample
+    // aligned float4 staging: image rows, sample strides and the base pointer must be multiples of 4 floats
+    if ((g.W & 3) || g.W < 4 || (in.sstride & 3) || ((uintptr_t)in.data & 15)) return -2;
     GView none{};
     if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
     if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
@@ -507,6 +603,9 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
 {
     if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks == 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
     if ((long long)g.Cin * (g.H + 2) * (g.W + 2) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
+    // aligned float4 (stride 2: float2) staging of the gradient and of the conv output it is normalised with
+    const int wa = g.stride == 2 ? 1 : 3;
+    if ((g.Wo & wa) || g.Wo < (wa + 1) || (gy.gstride & wa) || ((uintptr_t)gy.ga & 15) || (gy.y && ((gy.ystride & wa) || ((uintptr_t)gy.y & 15)))) return -2;
     TView none{}; OutDesc od{};
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);

@@ -76,7 +76,7 @@ rep('''                              s_red[0][q][which] + s_red[1][q][which] + s
 }''')
 rep("    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1};",
     "    static long long* prof = [] { long long* p = nullptr; if (getenv(\"MFVI_PROF\")) { (void)hipMalloc((void**)&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();\n    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1, 0, 0, 0, prof};")
-rep("        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO_MF",
-    "        if (prof) { long long h[64]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost); fprintf(stderr, \"MODE %d KS %d mf %d th %d T %d tiles %d my %d chunks/tile %d\\n\", MODE, KS, MF_, TH_, A.tiles_per_block, A.n_tiles, my, (RED + 7) / 8); for (int w = 0; w < 8; ++w) { fprintf(stderr, \"wave %d:\", w); for (int i = 0; i < 8; ++i) fprintf(stderr, \" %lld\", h[w * 8 + i]); fprintf(stderr, \"\\n\"); } } \\\n        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO_MF")
+rep("        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO(MF_, TH_)",
+    "        if (prof) { long long h[64]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost); fprintf(stderr, \"MODE %d KS %d mf %d th %d T %d tiles %d my %d chunks/tile %d\\n\", MODE, KS, MF_, TH_, A.tiles_per_block, A.n_tiles, my, (RED + 7) / 8); for (int w = 0; w < 8; ++w) { fprintf(stderr, \"wave %d:\", w); for (int i = 0; i < 8; ++i) fprintf(stderr, \" %lld\", h[w * 8 + i]); fprintf(stderr, \"\\n\"); } } \\\n        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO(MF_, TH_)")
 rep("#include <cstdlib>", "#include <cstdlib>\n#include <cstdio>")
 open(p, 'w').write(s)
