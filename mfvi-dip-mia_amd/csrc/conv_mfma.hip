@@ -33,6 +33,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f2a __attribute__((ext_vector_type(2)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 4 floats at dword alignment (padded-gradient rows)
+constexpr int EPP = 36;                 // row pitch of the per-wave output transpose buffer: 16 channels x 32 pixels (+4)
 
 constexpr int pitch16(int n) { return ((n + 15) / 32) * 32 + 16; }      // smallest p >= n with p % 32 == 16
 
@@ -65,6 +67,7 @@ struct MfmaArgs {
     OutDesc out; float* dxp; long long dxp_sstride;
     int tiles_x, n_tiles, tiles_per_block;
     int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
+    int vec_out;                           // forward: output rows / strides / pointer allow aligned float4 stores
     int ow, rt, wpitch, nwin;              // FLAT tiles: output-domain width, rows per tile, window pitch, window positions
 };
 
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
     __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
     __shared__ double s_red[4][CT][2];
+    __shared__ __align__(16) float s_ep[FLAT ? 1 : 4][FLAT ? 1 : 16][FLAT ? 4 : EPP];    // rectangular tiles: epilogue transpose, one slab per consumer wave
 
     const ConvGeom& g = A.g;
     const int tid = threadIdx.x;
@@ -414,6 +418,88 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                 // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg.
                 // 32-bit element offsets from a wave-uniform base keep the address math out of the VGPR budget.
                 const int px0 = FLAT ? 0 : (tile % A.tiles_x) * TW, py0 = FLAT ? tile * A.rt : (tile / A.tiles_x) * TH;
+                // Rectangular tiles go through a per-wave LDS transpose so every global store instruction writes whole 128-byte
+                // rows (8 lanes x float4 per channel row): the direct D-layout stores are 64-byte partial lines and cost ~550
+                // cycles per instruction here (17 k cycles per tile).
+                bool done = false;
+                if constexpr (!FLAT) {
+                    float (*ep)[EPP] = s_ep[wv];
+                    const int ech = lane >> 3, ev4 = lane & 7;                  // read-back item: channel ech (+8), float4 column ev4
+                    if (MODE == 0 && A.vec_out) {
+                        const int HWo = g.Ho * g.Wo;
+                        float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HWo;
+                        float fs[MF][4], fq[MF][4];
+#pragma unroll
+                        for (int i = 0; i < MF; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { fs[i][r] = 0.f; fq[i][r] = 0.f; }
+#pragma unroll
+                        for (int i = 0; i < MF; ++i)
+#pragma unroll
+                            for (int rp = 0; rp < NF / 2; ++rp) {
+                                const int oy = py0 + wv * (TH / 4) + rp;
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const bool inside = oy < g.Ho && px0 + h * 16 + l15 < g.Wo;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int ml = i * 16 + l4 * 4 + r;
+                                        const float v = acc[i][2 * rp + h][r] + s_bias[ml];
+                                        ep[l4 * 4 + r][h * 16 + l15] = v;
+                                        if (inside && ml < mt) { fs[i][r] += v; fq[i][r] = __builtin_fmaf(v, v, fq[i][r]); }
+                                    }
+                                }
+                                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const int ch = ech + 8 * u, ox = px0 + 4 * ev4;
+                                    if (i * 16 + ch < mt && oy < g.Ho && ox < g.Wo)
+                                        *reinterpret_cast<float4*>(yout + (i * 16 + ch) * HWo + oy * g.Wo + ox) = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        if (do_stats) {
+#pragma unroll
+                            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float a = fs[i][r], b = fq[i][r];
+#pragma unroll
+                                    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                                    if (l15 == 0) { s_red[wv][i * 16 + l4 * 4 + r][0] += (double)a; s_red[wv][i * 16 + l4 * 4 + r][1] += (double)b; }
+                                }
+                        }
+                        done = true;
+                    }
+                    if (MODE == 1) {
+                        const int Hp = g.H + 2 * P, Wp = g.W + 2 * P, HWp = Hp * Wp;
+                        float* __restrict__ o = A.dxp + (long long)k * A.dxp_sstride + (long long)m0 * HWp;
+#pragma unroll
+                        for (int i = 0; i < MF; ++i)
+#pragma unroll
+                            for (int rp = 0; rp < NF / 2; ++rp) {
+                                const int pr = py0 + wv * (TH / 4) + rp;
+#pragma unroll
+                                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) ep[l4 * 4 + r][h * 16 + l15] = acc[i][2 * rp + h][r];
+                                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const int ch = ech + 8 * u, pc = px0 + 4 * ev4;
+                                    if (i * 16 + ch < mt && pr < Hp && pc < Wp) {
+                                        float* dst = o + (i * 16 + ch) * HWp + pr * Wp + pc;
+                                        const float4 v = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
+                                        if (pc + 3 < Wp) { f4u w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *reinterpret_cast<f4u*>(dst) = w; }
+                                        else { dst[0] = v.x; if (pc + 1 < Wp) dst[1] = v.y; if (pc + 2 < Wp) dst[2] = v.z; }
+                                    }
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        done = true;
+                    }
+                }
+                if (!done) {
                 if (MODE == 0) {
                     const int HWo = g.Ho * g.Wo;
                     float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HWo;
@@ -474,6 +560,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                             }
                         }
                 }
+                            }
             }
             lds_barrier();
         }
@@ -507,6 +594,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     const int MOUT = MODE == 0 ? g.Cout : g.Cin, RED = MODE == 0 ? g.Cin : g.Cout;
     const int RED4 = (RED + 3) & ~3;
     MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1};
+    A.vec_out = MODE == 0 && (g.Wo & 3) == 0 && (out.sstride & 3) == 0 && ((uintptr_t)out.data & 15) == 0;
 
     // Pick the largest tile that still gives the chip enough blocks: big tiles amortise the in-kernel weight sampling
     // (each sampled weight is reused by every pixel of the tile), small ones keep 256 CUs busy.  When the whole slab of a
