@@ -336,3 +336,71 @@ def test_argument_errors(M):
         plan.forward(mu, mu, mu, z, 1, 0, 0, 3)
     with pytest.raises(L.MfviError):
         L.check(L.lib().mfvi_radon_forward(L.ptr(z), L.ptr(z), 1, 8, 16, 4, L.ptr(z), L.stream_ptr()))
+
+
+# --------------------------------------------------------------------------------------------------
+def _conv_bn_plan(M, cin, cout, H, W, n):
+    """z -> 1x1 conv -> BN+act -> 3x3 conv (under test) -> BN+act -> 1x1 conv -> out: every fused path of the MFMA kernels is live."""
+    P = M.Program()
+    zin = P.tensor(cin, H, W)
+    x = P.tensor(cin, H, W); P.conv(zin, x, 1, 1); P.set_bn(x, act=True)
+    y = P.tensor(cout, H, W); P.conv(x, y, 3, 1); P.set_bn(y, act=True)
+    out = P.tensor(2, H, W); P.conv(y, out, 1, 1)
+    return P, P.compile(zin, out, n), zin, out
+
+
+def _run_plan(plan, P, seed, n, z, dout):
+    mu = dev(0.1 * O.normal_fill(seed, 2, 0, 0, 0, P.n_vi)); rho = dev(-3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, P.n_vi))
+    bn = torch.ones(max(P.n_bn, 1), device="cuda")
+    o = plan.forward(mu, rho, bn, z, seed, 3, 0, n)
+    dmu = torch.zeros_like(mu); drho = torch.zeros_like(rho); dbn = torch.zeros_like(bn)
+    dz = torch.empty((n,) + tuple(z.shape), device="cuda")
+    plan.backward(mu, rho, bn, z, seed, 3, 0, n, dout, dmu, drho, dbn, dz=dz)
+    return host(o), host(dmu), host(drho), host(dz)
+
+
+@pytest.mark.parametrize("shape", [(36, 16, 64, 64), (68, 32, 32, 32), (132, 64, 16, 16)])
+def test_tilings_do_not_change_results(M, shape):
+    """Every tiling the autotuner may pick (rectangular / FLAT tiles, fragments, tiles per block, backward-weight variants)
+    computes the same numbers: forward bit-identical, gradients to summation-order rounding."""
+    cin, cout, H, W = shape
+    n, seed = 2, 77
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    enc = lambda a, b, c: a | b << 8 | c << 16
+    fwd_bwd = [(1, 8, 1), (1, 16, 1), (2, 8, 2), (3, 8, 1), (1, 8 | 128, 1), (1, 16 | 128, 1), (2, 8 | 128, 2)]
+    bww = [(1, 4, 1), (1, 8, 2), (2, 9, 1), (3, 9, 1), (3, 4, 2)]
+    for which, cands in ((0, fwd_bwd), (1, fwd_bwd), (2, bww)):
+        for cand in cands:
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc(*cand)))
+            got = _run_plan(plan, P, seed, n, z, dout)
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, 0))
+            assert relerr(got[0], ref[0]) < 1e-6, ("out", which, cand)          # BN statistics are summed in a different order
+            for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+                assert relerr(a, b) < 2e-5, (name, which, cand)
+
+
+def test_autotune_cache_and_reproducible_gradients(M, tmp_path):
+    cin, cout, H, W, n, seed = 36, 16, 32, 32, 4, 5
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    before = _run_plan(plan, P, seed, n, z, dout)
+    mu = dev(0.1 * O.normal_fill(seed, 2, 0, 0, 0, P.n_vi)); rho = dev(-3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, P.n_vi))
+    bn = torch.ones(P.n_bn, device="cuda")
+    cache = str(tmp_path / "tunes.json")
+    plan.autotune(mu, rho, bn, z, n, cache=cache)
+    tuned = plan.tunes()
+    assert os.path.exists(cache) and all(t is not None for t in tuned[1])       # the 3x3 layer got a tiling for all three passes
+    after = _run_plan(plan, P, seed, n, z, dout)
+    again = _run_plan(plan, P, seed, n, z, dout)
+    for a, b in zip(after, before):
+        assert relerr(a, b) < 2e-5
+    # weight gradients come from slabs + grad_finalize (no atomics); only the fp64 BN-statistic atomics can reorder
+    assert relerr(again[1], after[1]) < 1e-6 and relerr(again[2], after[2]) < 1e-6
+    P2, plan2, _, _ = _conv_bn_plan(M, cin, cout, H, W, n)
+    plan2.autotune(mu, rho, bn, z, n, cache=cache)                              # served from the cache
+    assert plan2.tunes() == tuned
