@@ -52,6 +52,9 @@ struct mfvi_plan {
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
     SampleEntry* samp_dev = nullptr; int n_samp = 0, samp_blocks = 0;    // layers whose weights are drawn once per pass
     long long wsamp_off = -1;                  // floats: sampled weights [max_samples][n_vi]
+    // identity of the draw currently held in the sampled-weight slab (set by forward, reused by the matching backward)
+    const void* samp_mu = nullptr; const void* samp_rho = nullptr; const void* samp_ws = nullptr;
+    uint64_t samp_seed = 0; uint32_t samp_step = 0, samp_k0 = 0; int samp_n = 0;
     GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
     std::vector<GradFinEntry> fin_uploaded;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
@@ -320,6 +323,7 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         ProfScope ps(plan, -1, PASS_SAMPLE, st);
         const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
         if (rc) { set_error("forward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+        plan->samp_mu = mu; plan->samp_rho = rho; plan->samp_ws = workspace; plan->samp_seed = seed; plan->samp_step = step; plan->samp_k0 = k0; plan->samp_n = n_samples;
     }
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
     for (size_t i = 0; i < plan->ops.size(); ++i) {
@@ -355,9 +359,12 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
-    // the weights of this pass, re-drawn from the same counters (the buffer may have been overwritten since the forward)
+    // the weights of this pass: the slab still holds them when the preceding forward was this very pass (same parameter
+    // buffers, counters, sample range and workspace); otherwise they are re-drawn from the same counters
     const bool presample = use_mfma() && sample_weights && plan->n_samp > 0;
-    if (presample) {
+    const bool held = plan->samp_mu == mu && plan->samp_rho == rho && plan->samp_ws == workspace && plan->samp_seed == seed &&
+                      plan->samp_step == step && plan->samp_k0 == k0 && plan->samp_n == n_samples;
+    if (presample && !held) {
         ProfScope ps(plan, -1, PASS_SAMPLE, st);
         const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
         if (rc) { set_error("backward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
@@ -514,6 +521,13 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
     if (e != hipSuccess) { set_error("autotune: %s", hipGetErrorString(e)); return (int)e; }
     rc = mfvi_backward(plan, mu, rho, bn, z, 1, 0, 0, n_samples, 1, workspace, dout, dmu, drho, dbn, nullptr, stream);
     if (rc) return rc;
+    // a cold GPU ramps its clocks over the first ~100 ms of work: candidates timed during the ramp would look slow and the
+    // choice would depend on their order, so run the real passes until the device has been busy for a while
+    for (int warm = 0; warm < 24 && !rc; ++warm) {
+        rc = mfvi_forward(plan, mu, rho, bn, z, 1, 0, 0, n_samples, 1, workspace, out, stream);
+        if (!rc) rc = mfvi_backward(plan, mu, rho, bn, z, 1, 0, 0, n_samples, 1, workspace, dout, dmu, drho, dbn, nullptr, stream);
+    }
+    if (rc) return rc;
     Ctx c{*plan, (char*)workspace, bn, z, n_samples};
     const RngKey key = base_key(1, 0, 0);
     hipEvent_t ea, eb;
@@ -549,12 +563,17 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
                 if (rc == -2) break;
                 if (rc == -3) continue;
                 if (rc) { set_error("autotune: op %d launch failed: %s", (int)i, rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad arguments"); goto done; }
-                (void)hipEventRecord(ea, st);
-                for (int r = 0; r < reps && !rc; ++r) rc = launch();
-                (void)hipEventRecord(eb, st);
-                float ms = 0.f;
-                e = hipEventSynchronize(eb);
-                if (e == hipSuccess) e = hipEventElapsedTime(&ms, ea, eb);
+                float ms = 1e30f;
+                for (int trial = 0; trial < 2 && !rc; ++trial) {      // best of two timings of `reps` launches: the choice must not flip on noise
+                    (void)hipEventRecord(ea, st);
+                    for (int r = 0; r < reps && !rc; ++r) rc = launch();
+                    (void)hipEventRecord(eb, st);
+                    float t_ms = 0.f;
+                    e = hipEventSynchronize(eb);
+                    if (e == hipSuccess) e = hipEventElapsedTime(&t_ms, ea, eb);
+                    if (e != hipSuccess) break;
+                    if (t_ms < ms) ms = t_ms;
+                }
                 if (rc || e != hipSuccess) { set_error("autotune: op %d timing failed: %s", (int)i, hipGetErrorString(rc ? (hipError_t)rc : e)); rc = rc ? rc : (int)e; goto done; }
                 // backward-weight: every extra pixel strip is one more slab grad_finalize has to read (~2 TB/s there)
                 if (which == 2) ms += reps * (float)((double)strips_used * n_samples * o.part_stride * 4.0 / 2.0e12 * 1e3);

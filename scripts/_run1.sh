@@ -1,4 +1,6 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest.log 2>&1 || { tail -60 gpurun_out/pytest.log; exit 1; }
-tail -3 gpurun_out/pytest.log
+for i in 1 2 3; do
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$i.log 2>&1
+tail -1 gpurun_out/bench_$i.log | cut -c140-260
+done
