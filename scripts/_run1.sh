@@ -1,6 +1,4 @@
 set -e
 mkdir -p gpurun_out
-for i in 1 2 3; do
-timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$i.log 2>&1
-tail -1 gpurun_out/bench_$i.log | cut -c140-260
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q > gpurun_out/pytest.log 2>&1 || { tail -60 gpurun_out/pytest.log; exit 1; }
+tail -5 gpurun_out/pytest.log
