@@ -14,8 +14,8 @@ struct BwdCfg {
     static constexpr int TW = 32, TH = 8;        // padded-input pixels per block (one per thread)
     static constexpr int CIT = 16;               // input channels per block
     static constexpr int COC = 8;                // output channels per LDS stage
-    static constexpr int GT_H = (STRIDE == 1) ? TH + KS - 1 : TH / 2 + 2;
-    static constexpr int GT_W = (STRIDE == 1) ? TW + KS - 1 : TW / 2 + 2;
+    static constexpr int GT_H = (STRIDE == 1) ? TH + KS - 1 : TH / 2 + (KS + 1) / 2;
+    static constexpr int GT_W = (STRIDE == 1) ? TW + KS - 1 : TW / 2 + (KS + 1) / 2;
     static constexpr int GT_WP = GT_W | 1;
 };
 
@@ -167,6 +167,8 @@ int launch_conv_bwd_data(const GView& gy, const ConvGeom& g, const float* mu, co
     if (g.ks == 3 && g.stride == 1) LAUNCH(3, 1)
     else if (g.ks == 3 && g.stride == 2) LAUNCH(3, 2)
     else if (g.ks == 1 && g.stride == 1) LAUNCH(1, 1)
+    else if (g.ks == 5 && g.stride == 1) LAUNCH(5, 1)
+    else if (g.ks == 5 && g.stride == 2) LAUNCH(5, 2)
     else { set_error("conv_bwd_data: unsupported ksize %d stride %d", g.ks, g.stride); return -1; }
 #undef LAUNCH
     return (int)hipGetLastError();

@@ -178,6 +178,8 @@ int launch_conv_bwd_weight(const TView& in, const GView& gy, const ConvGeom& g, 
     if (g.ks == 3 && g.stride == 1) LAUNCH(3, 1)
     else if (g.ks == 3 && g.stride == 2) LAUNCH(3, 2)
     else if (g.ks == 1 && g.stride == 1) LAUNCH(1, 1)
+    else if (g.ks == 5 && g.stride == 1) LAUNCH(5, 1)
+    else if (g.ks == 5 && g.stride == 2) LAUNCH(5, 2)
     else { set_error("conv_bwd_weight: unsupported ksize %d stride %d", g.ks, g.stride); return -1; }
 #undef LAUNCH
     return (int)hipGetLastError();

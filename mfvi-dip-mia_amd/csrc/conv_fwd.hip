@@ -195,6 +195,8 @@ int launch_conv_fwd(const TView& in, const ConvGeom& g, const float* mu, const f
     if (g.ks == 3 && g.stride == 1) LAUNCH(3, 1)
     else if (g.ks == 3 && g.stride == 2) LAUNCH(3, 2)
     else if (g.ks == 1 && g.stride == 1) LAUNCH(1, 1)
+    else if (g.ks == 5 && g.stride == 1) LAUNCH(5, 1)
+    else if (g.ks == 5 && g.stride == 2) LAUNCH(5, 2)
     else { set_error("conv_fwd: unsupported ksize %d stride %d", g.ks, g.stride); return -1; }
 #undef LAUNCH
     return (int)hipGetLastError();

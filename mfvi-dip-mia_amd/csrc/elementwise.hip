@@ -40,10 +40,11 @@ __global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrc s0, FoldSrc s1
             const int p = src.pad, Hp = H + 2 * p, Wp = W + 2 * p;
             const float* __restrict__ base = src.d + (long long)k * src.sstride + (long long)c * Hp * Wp;
             if (p == 0) { d += base[(long long)r * Wp + q]; continue; }
-            // rows of the padded gradient that fold onto r: r+1 always, 0 if r == 1, H+1 if r == H-2
+            // padded rows that fold onto r under ReflectionPad2d(p): r+p always; p-r for 1 <= r <= p (top mirror);
+            // p + 2(H-1) - r for H-1-p <= r <= H-2 (bottom mirror).  Columns alike.
             int rows[3], cols[3], nr = 0, nc = 0;
-            rows[nr++] = r + 1; if (r == 1) rows[nr++] = 0; if (r == H - 2) rows[nr++] = H + 1;
-            cols[nc++] = q + 1; if (q == 1) cols[nc++] = 0; if (q == W - 2) cols[nc++] = W + 1;
+            rows[nr++] = r + p; if (r >= 1 && r <= p) rows[nr++] = p - r; if (r >= H - 1 - p && r <= H - 2) rows[nr++] = p + 2 * (H - 1) - r;
+            cols[nc++] = q + p; if (q >= 1 && q <= p) cols[nc++] = p - q; if (q >= W - 1 - p && q <= W - 2) cols[nc++] = p + 2 * (W - 1) - q;
             for (int a = 0; a < nr; ++a)
                 for (int b = 0; b < nc; ++b) d += base[(long long)rows[a] * Wp + cols[b]];
         }
@@ -420,14 +421,14 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
 {
     if (n_src < 1 || n_src > 2) { set_error("finalize_dx: %d gradient sources (1..2 supported)", n_src); return -1; }
     for (int i = 0; i < n_src; ++i)
-        if (srcs[i].pad < 0 || srcs[i].pad > 1) { set_error("finalize_dx: pad %d unsupported", srcs[i].pad); return -1; }
-    if (n_src > 0 && (x.H < 2 || x.W < 2) && (srcs[0].pad == 1 || (n_src > 1 && srcs[1].pad == 1))) {
-        set_error("finalize_dx: reflection padding needs H,W >= 2"); return -1;
-    }
+        if (srcs[i].pad < 0 || srcs[i].pad > 2) { set_error("finalize_dx: pad %d unsupported", srcs[i].pad); return -1; }
+    for (int i = 0; i < n_src; ++i)
+        if (srcs[i].pad > 0 && (x.H <= srcs[i].pad || x.W <= srcs[i].pad)) { set_error("finalize_dx: reflection padding %d needs H,W > %d", srcs[i].pad, srcs[i].pad); return -1; }
     const long long HW = (long long)x.H * x.W;
     FoldSrc s0 = srcs[0], s1 = n_src > 1 ? srcs[1] : srcs[0];
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    if ((x.W & 3) == 0 && x.H >= 2 && ((x.sstride | ga_sstride) & 3) == 0 && al16(x.data) && al16(ga)) {
+    const int maxpad = n_src > 1 ? (srcs[0].pad > srcs[1].pad ? srcs[0].pad : srcs[1].pad) : srcs[0].pad;      // the float4 kernel folds pad <= 1
+    if (maxpad <= 1 && (x.W & 3) == 0 && x.H >= 2 && ((x.sstride | ga_sstride) & 3) == 0 && al16(x.data) && al16(ga)) {
         dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), x.C, n_samples);
         hipLaunchKernelGGL(finalize_dx_vec_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
         return (int)hipGetLastError();

@@ -97,12 +97,12 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         if (d.type == MFVI_OP_CONV) {
             if (d.in0 < 0 || d.in0 >= n_t) return fail("plan: op %d: bad input tensor", i);
             const TensorInfo& x = p.t[d.in0]; const TensorInfo& y = p.t[d.out];
-            if (!((d.ksize == 3 && (d.stride == 1 || d.stride == 2)) || (d.ksize == 1 && d.stride == 1)))
-                return fail("plan: op %d: conv ksize %d stride %d not supported (3x3 s1/s2, 1x1 s1)", i, d.ksize, d.stride);
+            if (!(((d.ksize == 3 || d.ksize == 5) && (d.stride == 1 || d.stride == 2)) || (d.ksize == 1 && d.stride == 1)))
+                return fail("plan: op %d: conv ksize %d stride %d not supported (3x3 / 5x5 s1/s2, 1x1 s1)", i, d.ksize, d.stride);
             const int P = d.ksize / 2;
             const int Ho = (x.d.H + 2 * P - d.ksize) / d.stride + 1, Wo = (x.d.W + 2 * P - d.ksize) / d.stride + 1;
             if (Ho != y.d.H || Wo != y.d.W) return fail("plan: op %d: output spatial size (%d,%d) != expected (%d,%d)", i, y.d.H, y.d.W, Ho, Wo);
-            if (P > 0 && (x.d.H < 2 || x.d.W < 2)) return fail("plan: op %d: reflection padding needs H,W >= 2", i);
+            if (P > 0 && (x.d.H <= P || x.d.W <= P)) return fail("plan: op %d: reflection padding %d needs H,W > %d", i, P, P);
             const long long nw = (long long)y.d.C * x.d.C * d.ksize * d.ksize;
             if (d.w_off < 0 || d.w_off + nw > p.n_vi) return fail("plan: op %d: w_off out of range", i);
             if (d.b_off >= 0 && d.b_off + y.d.C > p.n_vi) return fail("plan: op %d: b_off out of range", i);
