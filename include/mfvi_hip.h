@@ -31,7 +31,7 @@ extern "C" {
 typedef struct mfvi_plan mfvi_plan;
 
 enum { MFVI_OP_CONV = 1, MFVI_OP_CONCAT_UP = 2 };
-enum { MFVI_UP_BILINEAR = 0 };
+enum { MFVI_UP_BILINEAR = 0, MFVI_UP_NEAREST = 1 };   /* nn.Upsample(scale_factor=2, mode=...) (models/skip.py:102) */
 enum { MFVI_TASK_DENOISE = 0, MFVI_TASK_SR = 1 };
 
 /* An activation tensor of the layer program, [C][H][W] per MC sample, stored RAW (conv output or
@@ -112,6 +112,12 @@ int mfvi_gaussian_nll(const float* out, const float* target, int n, int H, int W
                       float grad_scale, float* dout, double* nll_sum, void* stream);
 /* mse_loss(radon(out), sino) (bayesian_optimization.py:576, radon/radon.py:49-53): out[n][1][H][W],
  * theta_deg[T], sino[T][W]; scratch: n*T*W floats.  mse_sum += sum_i mse_i; dout = grad_scale * d mse_i/d out_i. */
+/* gaussian_nll_inpainting (utils/bayesian_utils.py:35-39) with the runner's sigmoid on the colour channels
+ * (bayesian_optimization.py:3033-3036): out[n][4][H][W] = 3 colour logits + 1 shared neg-log-variance, target[3][H][W],
+ * mask[mask_channels][H][W] (1 or 3, broadcast); mean over the 3*H*W elements.  Same accumulation / gradient contract as
+ * mfvi_gaussian_nll. */
+int mfvi_gaussian_nll_inpainting(const float* out, const float* target, const float* mask, int mask_channels, int n, int H, int W,
+                                 float grad_scale, float* dout, double* nll_sum, void* stream);
 int mfvi_radon_mse(const float* out, const float* sino, const float* theta_deg, int n, int H, int W, int T,
                    float grad_scale, float* scratch, float* dout, double* mse_sum, void* stream);
 int mfvi_radon_forward(const float* img, const float* theta_deg, int n, int H, int W, int T, float* sino, void* stream);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mfvi_plan_get_tune": (_I, [_P, _I, _I]),
     "mfvi_plan_set_tune": (_I, [_P, _I, _I, _I]),
     "mfvi_gaussian_nll": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "mfvi_gaussian_nll_inpainting": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_radon_mse": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "mfvi_radon_forward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "mfvi_radon_adjoint": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -291,9 +291,9 @@ struct FoldSrc { const float* d; long long sstride; int pad; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.
 int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,
                        int n_samples, hipStream_t st);
-int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int n_samples, hipStream_t st);
+int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int nearest, int n_samples, hipStream_t st);
 int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long ga_a_sstride, double* bsums_a,
-                         const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int n_samples, hipStream_t st);
+                         const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int nearest, int n_samples, hipStream_t st);
 struct BnGradEntry { long long bsums_off; long long bn_off; int C; int pad; };
 int launch_bn_param_grads(const BnGradEntry* table_dev, int n_entries, int max_c, const double* bsums_base, int n_samples,
                           float* dbn, hipStream_t st);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void up_coef(int d, int n, int& i0, int& i1, float& l
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, TView b, OutDesc out, int H, int W)
+__global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, TView b, OutDesc out, int H, int W, int nearest)
 {
     __shared__ ChanFwd s_ch;
     __shared__ double s_red[8];
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, 
             int y0, y1, x0, x1; float ly, lx;
             up_coef(r, b.H, y0, y1, ly); up_coef(q, b.W, x0, x1, lx);
             const float* __restrict__ p = b.data + (long long)k * b.sstride + (long long)(c - Ca) * b.H * b.W;
+            if (nearest) { y0 = y1 = r >> 1; x0 = x1 = q >> 1; ly = 0.f; lx = 0.f; }      // mode='nearest': src = floor(dst / 2)
             const float v00 = apply_fwd(ch, p[y0 * b.W + x0], b.act, b.slope), v01 = apply_fwd(ch, p[y0 * b.W + x1], b.act, b.slope);
             const float v10 = apply_fwd(ch, p[y1 * b.W + x0], b.act, b.slope), v11 = apply_fwd(ch, p[y1 * b.W + x1], b.act, b.slope);
             v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void concat_up_fwd_kernel(TView a, int has_a, 
 
 // concat_up forward for W % 4 == 0: every lane writes 4 consecutive pixels of one row.  The upsampled part reads the four
 // low-res columns q/2-1 .. q/2+2 (clamped) of two low-res rows and blends with the same arithmetic as the scalar kernel.
-__global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has_a, TView b, OutDesc out, int H, int W)
+__global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has_a, TView b, OutDesc out, int H, int W, int nearest)
 {
     __shared__ ChanFwd s_ch;
     __shared__ double s_red[8];
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has
             const int r = gi / W4, q = (gi - r * W4) * 4;
             int y0, y1; float ly;
             up_coef(r, b.H, y0, y1, ly);
+            if (nearest) { y0 = y1 = r >> 1; ly = 0.f; }
             const float* __restrict__ p = b.data + (long long)k * b.sstride + (long long)(c - Ca) * b.H * b.W;
             const int xb = (q >> 1) - 1;
             float lo[4], hi[4];
@@ -240,8 +242,9 @@ __global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has
             const float lxs[4] = {left ? 0.f : 0.75f, 0.25f, 0.75f, 0.25f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ia = (j == 0 && left) ? 1 : i0[j];
-                const float lx = lxs[j];
+                // mode='nearest': output columns q..q+3 copy low-res columns q/2, q/2, q/2+1, q/2+1 (lo[1], lo[1], lo[2], lo[2])
+                const int ia = nearest ? 1 + (j >> 1) : ((j == 0 && left) ? 1 : i0[j]);
+                const float lx = nearest ? 0.f : lxs[j];
                 const float v00 = lo[ia], v01 = lo[ia + 1], v10 = hi[ia], v11 = hi[ia + 1];
                 v[j] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
             }
@@ -270,7 +273,7 @@ constexpr int CB_ROWS = 2 * CB_TH + 2, CB_PITCH = CB_TW + 1;      // staged rows
 __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, int has_a, float* __restrict__ ga_a,
                                                             long long ga_a_sstride, double* __restrict__ bsums_a,
                                                             TView b, float* __restrict__ ga_b, long long ga_b_sstride,
-                                                            double* __restrict__ bsums_b, int tiles_x)
+                                                            double* __restrict__ bsums_b, int tiles_x, int nearest)
 {
     __shared__ ChanFwd s_ch;
     __shared__ ChanBwd s_cg;
@@ -362,10 +365,10 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
                 const int oy = 2 * m - 1 + q, ox = 2 * n - 1 + q;
                 float v = (q == 0 || q == 3) ? 0.25f : 0.75f;
                 if (oy < 0 || oy >= H) v = 0.f; else if ((m == 0 && q == 1) || (m == dst.H - 1 && q == 2)) v = 1.f;
-                wy[q] = v;
                 float u = (q == 0 || q == 3) ? 0.25f : 0.75f;
                 if (ox < 0 || ox >= W) u = 0.f; else if ((n == 0 && q == 1) || (n == dst.W - 1 && q == 2)) u = 1.f;
-                wx[q] = u;
+                if (nearest) { v = (q == 1 || q == 2) ? 1.f : 0.f; u = v; }      // adjoint of the 2x2 replication: rows 2m, 2m+1 only
+                wy[q] = v; wx[q] = u;
             }
             float d = 0.f;
 #pragma unroll
@@ -438,7 +441,7 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
     return (int)hipGetLastError();
 }
 
-int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int n_samples, hipStream_t st)
+int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int nearest, int n_samples, hipStream_t st)
 {
     const int H = 2 * b.H, W = 2 * b.W;
     const int Ct = (a ? a->C : 0) + b.C;
@@ -447,16 +450,16 @@ int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int n_samp
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if ((W & 3) == 0 && (out.sstride & 3) == 0 && al16(out.data) && (!a || ((a->sstride & 3) == 0 && al16(a->data)))) {
         dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), Ct, n_samples);
-        hipLaunchKernelGGL(concat_up_fwd_vec_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W);
+        hipLaunchKernelGGL(concat_up_fwd_vec_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W, nearest);
         return (int)hipGetLastError();
     }
     dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), Ct, n_samples);
-    hipLaunchKernelGGL(concat_up_fwd_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W);
+    hipLaunchKernelGGL(concat_up_fwd_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W, nearest);
     return (int)hipGetLastError();
 }
 
 int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long ga_a_sstride, double* bsums_a,
-                         const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int n_samples, hipStream_t st)
+                         const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int nearest, int n_samples, hipStream_t st)
 {
     const int Ct = (a ? a->C : 0) + b.C;
     if ((gc.W & 1) || ((gc.gstride | gc.ystride) & 1) || (a && ((a->sstride | ga_a_sstride) & 1))) {
@@ -465,7 +468,7 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
     dim3 grid((unsigned)(tiles_x * tiles_y), Ct, n_samples);
     TView av = a ? *a : b;
     hipLaunchKernelGGL(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
-                       ga_b_sstride, bsums_b, tiles_x);
+                       ga_b_sstride, bsums_b, tiles_x, nearest);
     return (int)hipGetLastError();
 }
 

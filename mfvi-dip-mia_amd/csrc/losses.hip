@@ -41,6 +41,40 @@ __global__ __launch_bounds__(256) void gaussian_nll_kernel(const float* __restri
     block_atomic_add(acc / (double)n, nll_sum, s_red);
 }
 
+
+// ---- gaussian_nll_inpainting: sigmoid on the 3 colour channels, one shared log-precision channel, mask ----
+__global__ __launch_bounds__(256) void gaussian_nll_inp_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                               const float* __restrict__ mask, int mask_channels, long long HW,
+                                                               float grad_scale, float* __restrict__ dout, double* __restrict__ nll_sum)
+{
+    __shared__ double s_red[8];
+    const int k = blockIdx.y;
+    const float* __restrict__ o = out + (long long)k * 4 * HW;
+    float* __restrict__ d = dout ? dout + (long long)k * 4 * HW : nullptr;
+    const float inv_n = 1.f / (float)(3 * HW);
+    double acc = 0;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+        const float sraw = o[3 * HW + p];
+        const float s = fminf(fmaxf(sraw, -20.f), 20.f);
+        const bool inside = (sraw >= -20.f) && (sraw <= 20.f);
+        const float e = expf(s);
+        float ds = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float m = sigmoid_f(o[c * HW + p]);
+            const float mk = mask[(mask_channels == 3 ? c : 0) * HW + p];
+            const float df = target[c * HW + p] - m;
+            acc += (double)((e * df * df - s) * mk);
+            if (d) {
+                d[c * HW + p] = grad_scale * (-2.f * e * df) * mk * m * (1.f - m) * inv_n;
+                ds += (e * df * df - 1.f) * mk;
+            }
+        }
+        if (d) d[3 * HW + p] = inside ? grad_scale * ds * inv_n : 0.f;
+    }
+    block_atomic_add(acc * (double)inv_n, nll_sum, s_red);
+}
+
 // ---- KL ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ mu, const float* __restrict__ rho, long long n,
                                                  float m0, float s0, double* __restrict__ kl_out)
@@ -347,6 +381,17 @@ int mfvi_gaussian_nll(const float* out, const float* target, int n, int H, int W
     if (dout && factor > 1) { hipError_t e = hipMemsetAsync(dout, 0, sizeof(float) * (size_t)n * 2 * H * W, st); if (e) return (int)e; }
     const long long npix = (long long)(H / factor) * (W / factor);
     hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nblocks(npix, 256), n), dim3(256), 0, st, out, target, H, W, factor, grad_scale, dout, nll_sum);
+    return (int)hipGetLastError();
+}
+
+int mfvi_gaussian_nll_inpainting(const float* out, const float* target, const float* mask, int mask_channels, int n, int H, int W,
+                                 float grad_scale, float* dout, double* nll_sum, void* stream)
+{
+    if (!out || !target || !mask || !nll_sum || n < 1 || H < 1 || W < 1 || (mask_channels != 1 && mask_channels != 3)) {
+        set_error("gaussian_nll_inpainting: bad arguments (n=%d H=%d W=%d mask_channels=%d)", n, H, W, mask_channels); return -1; }
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(gaussian_nll_inp_kernel, dim3(nblocks(HW, 256), n), dim3(256), 0, (hipStream_t)stream, out, target, mask, mask_channels, HW,
+                       grad_scale, dout, nll_sum);
     return (int)hipGetLastError();
 }
 

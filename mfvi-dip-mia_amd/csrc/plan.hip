@@ -111,7 +111,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
             p.t[d.in0].consumers.push_back(i);
         } else if (d.type == MFVI_OP_CONCAT_UP) {
             if (d.in1 < 0 || d.in1 >= n_t || d.in0 >= n_t) return fail("plan: op %d: bad input tensors", i);
-            if (d.up_mode != MFVI_UP_BILINEAR) return fail("plan: op %d: only bilinear upsampling is implemented", i);
+            if (d.up_mode != MFVI_UP_BILINEAR && d.up_mode != MFVI_UP_NEAREST) return fail("plan: op %d: unknown upsampling mode %d (bilinear, nearest)", i, d.up_mode);
             const TensorInfo& b = p.t[d.in1]; const TensorInfo& y = p.t[d.out];
             int Ca = 0;
             if (d.in0 >= 0) {
@@ -339,7 +339,7 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
-            rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, n_samples, st);
+            rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
         }
         if (rc) { if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc)); return rc; }
     }
@@ -420,7 +420,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
             }
             ProfScope ps(plan, i, PASS_CONCAT_BWD, st);
             rc = launch_concat_up_bwd(gc, o.d.in0 >= 0 ? &a : nullptr, ga_a, sa, bs_a, c.view(o.d.in1), c.farena() + b.ga_off, b.numel,
-                                      b.d.has_bn ? c.bsums() + b.stats_off : nullptr, n_samples, st);
+                                      b.d.has_bn ? c.bsums() + b.stats_off : nullptr, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
         }
         if (rc) { if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc)); return rc; }
     }

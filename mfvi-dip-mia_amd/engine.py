@@ -17,7 +17,11 @@ from . import _lib as L
 from .program import skip_program
 from .sharding import allreduce_sum_, shard_samples
 
-TASK_DEN, TASK_SR, TASK_CT = "den", "sr", "ct"
+TASK_DEN, TASK_SR, TASK_CT, TASK_INP = "den", "sr", "ct", "inp"
+# the inpainting runner's net (bayesian_optimization.py:2970-2998): 6 scales, no skip branches, 5x5 down filters, nearest upsampling,
+# no 1x1 up convolutions, 3 colour logits + 1 log-precision channel
+INP_NET = dict(nd=(16, 32, 64, 128, 128, 128), nu=(16, 32, 64, 128, 128, 128), ns=(0, 0, 0, 0, 0, 0), fd=5, fu=3, need1x1_up=False,
+               upsample_mode="nearest")
 
 
 class ElboEngine:
@@ -34,8 +38,9 @@ class ElboEngine:
         # prior scale exactly as bayesian_optimization.py:1335-1336 + modules/module.py:38, rounded to fp32
         import numpy as np
         self.prior_sigma = float(np.float32(math.sqrt(temp) * sigma + 1e-6))
-        n_out = 1 if task == TASK_CT else 2
-        kw = dict(net_kwargs or {})
+        n_out = {TASK_CT: 1, TASK_INP: 4}.get(task, 2)
+        kw = dict(INP_NET if task == TASK_INP else {})
+        kw.update(net_kwargs or {})
         self.prog, self.zin, self.zout, self.names = skip_program(H, W, input_depth, n_out, **kw)
         self.chunk = min(self.K_local, samples_per_launch or self.K_local)
         self.plan = self.prog.compile(self.zin, self.zout, self.chunk)
@@ -79,9 +84,16 @@ class ElboEngine:
         L.check(lib.mfvi_uniform_fill(self.seed, 0, 0, 0, self.z0.numel(), 0.1, L.ptr(self.z0), sp))
         self.m.zero_(); self.v.zero_(); self.t = 0
 
-    def set_target(self, target):
-        """den: noisy image [H][W]; sr: low-res image [H/f][W/f]; ct: sinogram [T][W]."""
+    def set_target(self, target, mask=None):
+        """den: noisy image [H][W]; sr: low-res image [H/f][W/f]; ct: sinogram [T][W]; inp: colour image [3][H][W] with
+        mask [1|3][H][W] (1 = known pixel, rounded like bayesian_optimization.py:3024)."""
         self.target = target.contiguous().float().cuda()
+        if self.task == TASK_INP:
+            if mask is None:
+                raise ValueError("the inpainting task needs a mask")
+            self.mask = mask.contiguous().float().cuda().round()
+            if self.mask.dim() == 2:
+                self.mask = self.mask[None]
 
     # -------------------------------------------------------------------------------------------
     def forward_only(self, step=None, perturb=True):
@@ -102,6 +114,9 @@ class ElboEngine:
             L.check(lib.mfvi_gaussian_nll(L.ptr(self.out), L.ptr(self.target), n, self.H, self.W, 1, scale, L.ptr(self.dout), L.ptr(self.acc), sp))
         elif self.task == TASK_SR:
             L.check(lib.mfvi_gaussian_nll(L.ptr(self.out), L.ptr(self.target), n, self.H, self.W, self.sr_factor, scale, L.ptr(self.dout), L.ptr(self.acc), sp))
+        elif self.task == TASK_INP:
+            L.check(lib.mfvi_gaussian_nll_inpainting(L.ptr(self.out), L.ptr(self.target), L.ptr(self.mask), self.mask.shape[0], n, self.H, self.W,
+                                                     scale, L.ptr(self.dout), L.ptr(self.acc), sp))
         else:
             L.check(lib.mfvi_radon_mse(L.ptr(self.out), L.ptr(self.target), L.ptr(self.theta), n, self.H, self.W, self.theta.numel(), scale,
                                        L.ptr(self.ct_scratch), L.ptr(self.dout), L.ptr(self.acc), sp))

@@ -49,9 +49,10 @@ class Program:
                              up_mode=0, w_off=w_off, b_off=b_off))
         return lid
 
-    def concat_up(self, in0, in1, out_id):
+    def concat_up(self, in0, in1, out_id, mode="bilinear"):
+        """Concat(in0, Upsample(x2, mode)(in1)); in0=None is a plain upsample (skip() with num_channels_skip == 0)."""
         self.ops.append(dict(type=L.OP_CONCAT_UP, in0=-1 if in0 is None else in0, in1=in1, out=out_id, ksize=0, stride=0,
-                             layer_id=0, up_mode=0, w_off=0, b_off=-1))
+                             layer_id=0, up_mode={"bilinear": 0, "nearest": 1}[mode], w_off=0, b_off=-1))
 
     def conv_out_hw(self, in_id, ksize, stride):
         t = self.tensors[in_id]
@@ -166,27 +167,33 @@ class Plan:
 
 
 def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(16, 32, 64, 128, 128), ns=(4, 4, 4, 4, 4),
-                 fd=3, fu=3, fs=1):
+                 fd=3, fu=3, fs=1, need1x1_up=True, upsample_mode="bilinear"):
     """The skip() hour-glass of the reference (models/skip.py:58-134) as a layer program, in module order:
-    per scale  skip-conv/BN/act, down-conv(s2)/BN/act, conv/BN/act, [deeper scale], Upsample, Concat, BN,
-    up-conv/BN/act, 1x1-conv/BN/act; then the final 1x1 conv.  Returns (program, input_id, output_id, tensor-id map)."""
+    per scale  [skip-conv/BN/act], down-conv(s2)/BN/act, conv/BN/act, [deeper scale], Upsample, [Concat], BN,
+    up-conv/BN/act, [1x1-conv/BN/act]; then the final 1x1 conv.  ns[i] == 0 drops the skip branch and its Concat
+    (models/skip.py:62-66), need1x1_up / filter sizes / upsample_mode as in the inpainting runner
+    (bayesian_optimization.py:2970-2998).  Returns (program, input_id, output_id, tensor-id map)."""
     P = Program()
     names = {}
     zin = P.tensor(input_depth, H, W)
 
     def scale(i, x):
         h, w = P.tensors[x]["H"], P.tensors[x]["W"]
-        s = P.tensor(ns[i], *P.conv_out_hw(x, fs, 1)); P.conv(x, s, fs, 1); P.set_bn(s, act=True)
+        s = None
+        if ns[i]:
+            s = P.tensor(ns[i], *P.conv_out_hw(x, fs, 1)); P.conv(x, s, fs, 1); P.set_bn(s, act=True)
         d1 = P.tensor(nd[i], *P.conv_out_hw(x, fd, 2)); P.conv(x, d1, fd, 2); P.set_bn(d1, act=True)
         d2 = P.tensor(nd[i], *P.conv_out_hw(d1, fd, 1)); P.conv(d1, d2, fd, 1); P.set_bn(d2, act=True)
         deep, kk = d2, nd[i]
         if i < len(nd) - 1:
             deep, kk = scale(i + 1, d2), nu[i + 1]
-        cat = P.tensor(ns[i] + kk, h, w); P.concat_up(s, deep, cat); P.set_bn(cat, act=False)
+        cat = P.tensor(ns[i] + kk, h, w); P.concat_up(s, deep, cat, upsample_mode); P.set_bn(cat, act=False)
         u = P.tensor(nu[i], *P.conv_out_hw(cat, fu, 1)); P.conv(cat, u, fu, 1); P.set_bn(u, act=True)
-        u1 = P.tensor(nu[i], h, w); P.conv(u, u1, 1, 1); P.set_bn(u1, act=True)
-        names[i] = dict(skip=s, d1=d1, d2=d2, cat=cat, up=u, up1=u1)
-        return u1
+        top_i = u
+        if need1x1_up:
+            top_i = P.tensor(nu[i], h, w); P.conv(u, top_i, 1, 1); P.set_bn(top_i, act=True)
+        names[i] = dict(skip=s, d1=d1, d2=d2, cat=cat, up=u, up1=top_i)
+        return top_i
 
     top = scale(0, zin)
     out = P.tensor(n_out, H, W); P.conv(top, out, 1, 1)

@@ -154,6 +154,26 @@ def upsample2_bwd(dy):
     lib().oracle_upsample2_bwd(_p(dy), c, Ho // 2, Wo // 2, _p(dx)); return dx
 
 
+def upsample2_nearest_fwd(x):
+    x = _f(x); c, H, W = x.shape; y = np.empty((c, 2 * H, 2 * W), np.float32)
+    lib().oracle_upsample2_nearest_fwd(_p(x), c, H, W, _p(y)); return y
+
+
+def upsample2_nearest_bwd(dy):
+    dy = _f(dy); c, Ho, Wo = dy.shape; dx = np.empty((c, Ho // 2, Wo // 2), np.float32)
+    lib().oracle_upsample2_nearest_bwd(_p(dy), c, Ho // 2, Wo // 2, _p(dx)); return dx
+
+
+def gaussian_nll_inp(out4, target3, mask, scale=1.0, want_grad=False):
+    """sigmoid on out4[:3] + gaussian_nll_inpainting; mask (1|3, H, W)."""
+    out4, target3, mask = _f(out4), _f(target3), _f(mask)
+    HW = out4.shape[1] * out4.shape[2]
+    d = np.empty_like(out4) if want_grad else None
+    lib().oracle_gaussian_nll_inp.restype = C.c_double
+    v = lib().oracle_gaussian_nll_inp(_p(out4), _p(target3), _p(mask), C.c_int(mask.shape[0]), C.c_long(HW), C.c_double(scale), _p(d))
+    return (v, d) if want_grad else v
+
+
 def kl(mu, rho, prior_sigma, prior_mu=0.0, scale=0.0, want_grad=False):
     mu, rho = _f(mu).ravel(), _f(rho).ravel()
     dmu = np.zeros_like(mu) if want_grad else None; drho = np.zeros_like(rho) if want_grad else None
