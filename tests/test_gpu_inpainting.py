@@ -146,3 +146,33 @@ def test_inpainting_engine_runs_and_descends(M):
     for _ in range(30):
         eng.step(); losses.append(eng.losses()[0])
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_inpainting_net_against_reference_golden(M, golden_dir):
+    """The reference's own skip() built with the inpainting runner's options (3 scales, 24x24) wrapped in MeanFieldVI, with
+    the runner's sigmoid + gaussian_nll_inpainting: output, loss and every gradient (oracle/make_golden.py::golden_inpainting)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "inpainting.npz"), allow_pickle=False)
+    H = W = 24; seed = 21
+    P, zin, zout, _ = M.program.skip_program(H, W, input_depth=8, n_out=4, nd=(8, 16, 16), nu=(8, 16, 16), ns=(0, 0, 0), fd=5, fu=3,
+                                             need1x1_up=False, upsample_mode="nearest")
+    plan = P.compile(zin, zout, 1)
+    mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, P.n_vi); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, P.n_vi)
+    gg = O.normal_fill(seed, 2, 7, 0, 0, P.n_bn); bn = np.zeros(P.n_bn, np.float32)
+    for b in P.bns:
+        c, off = b["C"], b["off"]
+        bn[off:off + c] = 1.0 + 0.1 * gg[off:off + c]; bn[off + c:off + 2 * c] = 0.1 * gg[off + c:off + 2 * c]
+    z = O.normal_fill(seed, 2, 2, 0, 0, 8 * H * W).reshape(8, H, W)
+    tgt = O.uniform_fill(312, 1, 0, 0, 3 * H * W).reshape(3, H, W)
+    mask = (O.uniform_fill(312, 2, 0, 0, H * W).reshape(1, H, W) > 0.25).astype(np.float32)
+    d_mu, d_rho, d_bn, d_z, d_t, d_m = dev(mu), dev(rho), dev(bn), dev(z), dev(tgt), dev(mask)
+    out = plan.forward(d_mu, d_rho, d_bn, d_z, seed, 4, 0, 1)
+    assert relerr(out[0].cpu().numpy(), g["net_out"]) < 1e-4
+    L = M._lib
+    dout = torch.empty_like(out); acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    L.check(L.lib().mfvi_gaussian_nll_inpainting(L.ptr(out), L.ptr(d_t), L.ptr(d_m), 1, 1, H, W, 1.0, L.ptr(dout), L.ptr(acc), L.stream_ptr()))
+    assert abs(float(acc) - float(g["net_nll"])) < 1e-4 * max(abs(float(g["net_nll"])), 1e-2)
+    dmu = torch.zeros_like(d_mu); drho = torch.zeros_like(d_rho); dbn = torch.zeros_like(d_bn); dz = torch.empty((1, 8, H, W), device="cuda")
+    plan.backward(d_mu, d_rho, d_bn, d_z, seed, 4, 0, 1, dout, dmu, drho, dbn, dz=dz)
+    for got, key in ((dmu, "net_dmu"), (drho, "net_drho"), (dbn, "net_dbn"), (dz[0], "net_dz")):
+        assert relerr(got.cpu().numpy(), g[key]) < 2e-3, key              # fp32 reference, LeakyReLU kinks over 3x3 maps

@@ -328,7 +328,7 @@ def test_argument_errors(M):
     P = M.Program(); a = P.tensor(4, 8, 8); b = P.tensor(4, 9, 9); P.conv(a, b, 3, 1)
     with pytest.raises(L.MfviError, match="spatial size"):
         P.compile(a, b, 1)
-    P = M.Program(); a = P.tensor(4, 8, 8); b = P.tensor(4, 8, 8); P.conv(a, b, 5, 1)
+    P = M.Program(); a = P.tensor(4, 8, 8); b = P.tensor(4, 8, 8); P.conv(a, b, 7, 1)
     with pytest.raises(L.MfviError, match="not supported"):
         P.compile(a, b, 1)
     P = M.Program(); a = P.tensor(4, 8, 8); b = P.tensor(4, 8, 8); P.conv(a, b, 3, 1)

@@ -190,3 +190,36 @@ def test_trajectory(golden_dir, name):
     # so parameters are compared to within one step (lr = 1e-3 absolute); the loss trajectory above is tight.
     assert np.abs(p[:n_vi] - g["mu"]).max() < 1e-3 and np.abs(p[n_vi:2 * n_vi] - g["rho"]).max() < 1e-3
     assert np.abs(p[:n_vi] - g["mu"]).mean() < 2e-6
+
+
+def test_inpainting_ops(golden_dir):
+    """The ops only the inpainting variant uses (5x5 Conv2dRT, nearest upsampling, sigmoid + masked NLL) against the
+    reference's own modules (oracle/make_golden.py::golden_inpainting)."""
+    g = load(golden_dir, "inpainting")
+    for ci in range(2):
+        cin, cout, k, stride, H, W = [int(v) for v in g[f"conv{ci}_shape"]]
+        seed = 300 + ci; nw = cout * cin * k * k
+        mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+        x = O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W)
+        ew = O.eps(seed, 5, 2, 0, 0, nw); eb = O.eps(seed, 5, 2, 0, 1, cout)
+        w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, k, k); b = O.reparam(mu[nw:], rho[nw:], eb)
+        y = O.conv_fwd(x, w, b, stride)
+        assert relerr(y, g[f"conv{ci}_y"]) < RTOL, ci
+        dy = O.normal_fill(seed, 2, 3, 0, 0, y.size).reshape(y.shape)
+        dx, dw, db = O.conv_bwd(x, w, stride, dy)
+        sig = 1 / (1 + np.exp(-rho.astype(np.float64)))
+        assert relerr(dx, g[f"conv{ci}_dx"]) < RTOL, ci
+        assert relerr(np.concatenate([dw.ravel(), db]), g[f"conv{ci}_dmu"]) < RTOL, ci
+        assert relerr(np.concatenate([dw.ravel() * ew * sig[:nw], db * eb * sig[nw:]]), g[f"conv{ci}_drho"]) < RTOL, ci
+    x = O.normal_fill(310, 2, 0, 0, 0, 3 * 5 * 7).reshape(3, 5, 7)
+    assert np.array_equal(O.upsample2_nearest_fwd(x), g["up_y"])
+    dy = O.normal_fill(310, 2, 1, 0, 0, 3 * 10 * 14).reshape(3, 10, 14)
+    assert relerr(O.upsample2_nearest_bwd(dy), g["up_dx"]) < 1e-6
+    H, W = 12, 20
+    o = (2.0 * O.normal_fill(311, 2, 0, 0, 0, 4 * H * W)).reshape(4, H, W).copy(); o[3, 0, :4] = [25.0, -30.0, 19.9, 0.0]
+    tgt = O.uniform_fill(311, 1, 0, 0, 3 * H * W).reshape(3, H, W)
+    for mc in (1, 3):
+        mask = (O.uniform_fill(311, 2 + mc, 0, 0, mc * H * W).reshape(mc, H, W) > 0.3).astype(np.float32)
+        v, d = O.gaussian_nll_inp(o, tgt, mask, want_grad=True)
+        assert abs(v - float(g[f"nll_mask{mc}"])) < 2e-5 * abs(float(g[f"nll_mask{mc}"]))
+        assert relerr(d, g[f"nll_mask{mc}_dout"]) < RTOL
