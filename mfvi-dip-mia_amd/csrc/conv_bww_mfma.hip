@@ -16,6 +16,13 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f2a __attribute__((ext_vector_type(2)));
+// LDS planes are pitched == 2 (mod 32) floats: rows are 8-byte aligned, so a staged float4 goes out as two ds_write_b64
+__device__ __forceinline__ void lds_store4(float* p, float a, float b, float c, float d)
+{
+    f2a lo, hi; lo.x = a; lo.y = b; hi.x = c; hi.y = d;
+    *reinterpret_cast<f2a*>(p) = lo; *reinterpret_cast<f2a*>(p + 2) = hi;
+}
 
 constexpr int pitch2(int n) { return ((n + 29) / 32) * 32 + 2; }        // smallest p >= n with p % 32 == 2
 static_assert(pitch2(256) == 258 && pitch2(340) == 354 && pitch2(2) == 2 && pitch2(3) == 34, "pitch2");
@@ -28,8 +35,13 @@ struct WCfg {
     static constexpr int CIB = 16 * NB;                                   // input channels per block
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
     static constexpr int IN_TW = (TW - 1) * STRIDE + KS;
+    // The input window is stored with rows starting at an ALIGNED column (4 left of the tile when there is a halo), so the
+    // specialised producers can stage it with float4 loads / ds_write_b128; the first column a tap needs sits at XOFF.
+    static constexpr int HALO4 = KS > 1 ? 4 : 0;
+    static constexpr int XOFF = HALO4 ? HALO4 - KS / 2 : 0;
+    static constexpr int WV = (XOFF + IN_TW + 3) / 4 * 4;                  // 40 (3x3), 68 (3x3 stride 2), 32 (1x1)
     static constexpr int GPLANE = pitch2(TH * TW);
-    static constexpr int XPLANE = pitch2(IN_TH * IN_TW);
+    static constexpr int XPLANE = pitch2(IN_TH * WV);
     static constexpr int ROW = CIB * KK;
     static constexpr int STAGE = 16 * GPLANE + CIB * XPLANE;
     static constexpr int ROWP = ROW + 2;                                   // 4 * ROWP == 8 (mod 32): the 4 row groups of a wave spread over banks
@@ -47,7 +59,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
 {
     using Cfg = WCfg<KS, STRIDE, NB, NT>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH, KK = Cfg::KK, P = KS / 2, IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW;
-    constexpr int GPLANE = Cfg::GPLANE, XPLANE = Cfg::XPLANE, ROW = Cfg::ROW, CIB = Cfg::CIB;
+    constexpr int GPLANE = Cfg::GPLANE, XPLANE = Cfg::XPLANE, ROW = Cfg::ROW, CIB = Cfg::CIB, WV = Cfg::WV, XOFF = Cfg::XOFF;
     constexpr int NS = SPEC ? NT / 2 : NT;            // staging threads
     constexpr int NW = (SPEC ? NT / 2 : NT) / 64;     // MFMA waves
     static_assert(!SPEC || NT == 512, "specialised variant is built for 8 waves");
@@ -134,8 +146,9 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         for (int q = 0; q < NPOS; ++q) {
             const int p = ts + NS * q;
             if (p < IN_TH * IN_TW) {
+                const int iy = p / IN_TW, lp = iy * WV + (p - iy * IN_TW) + XOFF;
 #pragma unroll
-                for (int c = 0; c < CIB; ++c) s_x[c * XPLANE + p] = c < cit ? apply_fwd(s_chx[c], xr[q][c], in.act, in.slope) : 0.f;
+                for (int c = 0; c < CIB; ++c) s_x[c * XPLANE + lp] = c < cit ? apply_fwd(s_chx[c], xr[q][c], in.act, in.slope) : 0.f;
             }
         }
     };
@@ -143,14 +156,14 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         for (int ks = wv; ks < TH * (TW / 4); ks += NW) {
             const int row = ks / (TW / 4), c4 = (ks % (TW / 4)) * 4;
             const float a = s_g[l15 * GPLANE + row * TW + c4 + l4];
-            const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * IN_TW + (c4 + l4) * STRIDE;
+            const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * WV + (c4 + l4) * STRIDE + XOFF;
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx)
-                        acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[b * 16 * XPLANE + ky * IN_TW + kx], acc[b][ky * KS + kx], 0, 0, 0);
+                        acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[b * 16 * XPLANE + ky * WV + kx], acc[b][ky * KS + kx], 0, 0, 0);
             if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);
         }
     };
@@ -161,65 +174,74 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             // Producer wave pw stages input channels [pw*CPW, (pw+1)*CPW) and gradient channels [pw*4, pw*4+4): the channel is
             // wave-uniform, so its BN constants sit in registers and every element costs fma + select + one LDS store.
             constexpr int CPW = CIB / 4;                                  // input channels per producer wave
-            constexpr int NPX = (IN_TH * IN_TW + 63) / 64;                // passes of 64 lanes over the input tile
-            constexpr int NPG = PIX / 64;                                 // passes over the output-pixel tile
+            // aligned float4 items: input window row iy, float4 column v (NV4 per row); dy tile row, float4 column (TW/4 per row).
+            // A float4 is wholly inside or outside the image (launcher: W, Wo multiples of 4); reflection needs one element of
+            // an outside float4 (column -1 <- x[1], column W <- x[W-2]), taken from the neighbouring inside one.
+            constexpr int NV4 = WV / 4, NXI = IN_TH * NV4, NPX = (NXI + 63) / 64;      // input items / passes of 64 lanes
+            constexpr int NGI = PIX / 4, NPG = (NGI + 63) / 64;                        // dy items / passes
             const int pw = wv - NW;
             __builtin_amdgcn_s_setprio(2);                                // younger half of the workgroup: do not starve behind the MFMA stream
-            float pxr[CPW][NPX], pgr[4][NPG], pyr[4][NPG];
-            int pxo[NPX], pgo[NPG];
-            ChanFwd cx[CPW]; ChanBwd cgk[4];
+            float4 pxr[CPW][NPX], pgr[4][NPG], pyr[4][NPG];
+            int pxo[NPX], pgo[NPG];                                       // element offsets; input: low 2 bits = 1 left / 2 right reflected
             __syncthreads();                                             // (S0) channel tables visible
-#pragma unroll
-            for (int i = 0; i < CPW; ++i) cx[i] = s_chx[pw * CPW + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cgk[i] = s_chg[pw * 4 + i];
             auto pfetch = [&](int tile) {
                 const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
 #pragma unroll
                 for (int j = 0; j < NPG; ++j) {
-                    const int px = lane + 64 * j, yy = oy0 + px / TW, xx = ox0 + (px % TW);
+                    const int q = min(lane + 64 * j, NGI - 1), yy = oy0 + q / (TW / 4), xx = ox0 + (q % (TW / 4)) * 4;
                     pgo[j] = (yy < Ho && xx < Wo) ? yy * Wo + xx : -1;
                     const int gsafe = max(pgo[j], 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int off = (co0 + min(pw * 4 + i, cot - 1)) * HWo + gsafe;
-                        pgr[i][j] = gap[off];
-                        pyr[i][j] = yp ? yp[off] : 0.f;
+                        pgr[i][j] = *reinterpret_cast<const float4*>(gap + off);
+                        pyr[i][j] = yp ? *reinterpret_cast<const float4*>(yp + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
+                const int ax0 = ox0 * STRIDE - Cfg::HALO4;
 #pragma unroll
                 for (int j = 0; j < NPX; ++j) {
-                    const int p = lane + 64 * j;
-                    pxo[j] = -1;
-                    int xsafe = 0;
-                    if (p < IN_TH * IN_TW) {
-                        const int iy = p / IN_TW, ix = p - iy * IN_TW;
-                        int gyy = reflect_idx(oy0 * STRIDE + iy - P, H), gxx = reflect_idx(ox0 * STRIDE + ix - P, W);
-                        gyy = min(max(gyy, 0), H - 1); gxx = min(max(gxx, 0), W - 1);         // overhang meets dy == 0
-                        pxo[j] = xsafe = gyy * W + gxx;
-                    }
+                    const int q = min(lane + 64 * j, NXI - 1), iy = q / NV4, v = q - iy * NV4;
+                    int gyy = reflect_idx(oy0 * STRIDE + iy - P, H); gyy = min(max(gyy, 0), H - 1);      // overhang meets dy == 0
+                    int gx = ax0 + 4 * v, flag = 0;
+                    if (gx < 0) { flag = 1; gx = 0; } else if (gx >= W) { flag = gx == W ? 2 : 0; gx = W - 4; }
+                    pxo[j] = (gyy * W + gx) | flag;
 #pragma unroll
-                    for (int i = 0; i < CPW; ++i) pxr[i][j] = xin[(long long)(ci0 + min(pw * CPW + i, cit - 1)) * HW + xsafe];
+                    for (int i = 0; i < CPW; ++i)
+                        pxr[i][j] = *reinterpret_cast<const float4*>(xin + (long long)(ci0 + min(pw * CPW + i, cit - 1)) * HW + (pxo[j] & ~3));
                 }
             };
             auto pstage = [&]() {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int c = pw * 4 + i;
+                    const ChanBwd cgk = s_chg[c];                     // wave-uniform: one LDS read per channel and tile
 #pragma unroll
                     for (int j = 0; j < NPG; ++j) {
-                        float v = 0.f;
-                        if (pgo[j] >= 0 && c < cot) v = yp ? apply_bwd(cgk[i], pgr[i][j], pyr[i][j]) : pgr[i][j];
-                        s_g[c * GPLANE + lane + 64 * j] = v;
+                        const int q = lane + 64 * j;
+                        float e[4] = {pgr[i][j].x, pgr[i][j].y, pgr[i][j].z, pgr[i][j].w};
+                        if (yp) {
+                            const float yy[4] = {pyr[i][j].x, pyr[i][j].y, pyr[i][j].z, pyr[i][j].w};
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) e[l] = apply_bwd(cgk, e[l], yy[l]);
+                        }
+                        if (pgo[j] < 0 || c >= cot) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+                        if (64 * (j + 1) <= NGI || q < NGI) lds_store4(s_g + c * GPLANE + 4 * q, e[0], e[1], e[2], e[3]);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < CPW; ++i) {
                     const int c = pw * CPW + i;
+                    const ChanFwd cx = s_chx[c];
 #pragma unroll
                     for (int j = 0; j < NPX; ++j) {
-                        const int p = lane + 64 * j;
-                        if (p < IN_TH * IN_TW) s_x[c * XPLANE + p] = c < cit ? apply_fwd(cx[i], pxr[i][j], in.act, in.slope) : 0.f;
+                        const int q = lane + 64 * j, flag = pxo[j] & 3;
+                        float e[4] = {pxr[i][j].x, pxr[i][j].y, pxr[i][j].z, pxr[i][j].w};
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) e[l] = c < cit ? apply_fwd(cx, e[l], in.act, in.slope) : 0.f;
+                        if (flag == 1) e[3] = e[1];                       // column -1 <- x[1]
+                        else if (flag == 2) e[0] = e[2];                  // column W  <- x[W-2]
+                        if (64 * (j + 1) <= NXI || q < NXI) lds_store4(s_x + c * XPLANE + 4 * q, e[0], e[1], e[2], e[3]);
                     }
                 }
             };
@@ -310,6 +332,10 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
         const int nb = g.Cin > 32 ? 3 : (g.Cin > 16 ? 2 : 1);
         cfg = nb | ((nb >= 2 ? 9 : 4) << 8) | ((nb >= 2 ? 1 : 6) << 16);
     }
+    // aligned float4 staging of the specialised variant: image rows, sample strides and base pointers multiples of 4 floats
+    const bool vec_ok = !(g.W & 3) && g.W >= 4 && !(g.Wo & 3) && !(in.sstride & 3) && !((uintptr_t)in.data & 15) && !(gy.gstride & 3) &&
+                        !((uintptr_t)gy.ga & 15) && (!gy.y || (!(gy.ystride & 3) && !((uintptr_t)gy.y & 15)));
+    if (!forced && !vec_ok) cfg = (cfg & ~0xff00) | (4 << 8);      // heuristic falls back to the 4-wave variant
     const int nb = cfg & 255, wfield = (cfg >> 8) & 255, target = ((cfg >> 16) & 255) * 256;
     const bool spec = wfield == 9;
     const int nt = spec ? 512 : wfield * 64;
@@ -318,6 +344,7 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
         using Cfg = WCfg<KS_, S_, NB_, NT_>;                                                                                   \
         constexpr size_t lds_bytes = sizeof(float) * Cfg::LDS_FLOATS;                                                          \
         if (lds_bytes > 150 * 1024) return -3;                                                                                 \
+        if (SP_ && !vec_ok) return -3;                                         /* specialised producers stage aligned float4 */ \
         const int tiles_x = (g.Wo + Cfg::TW - 1) / Cfg::TW, tiles_y = (g.Ho + Cfg::TH - 1) / Cfg::TH;                          \
         const int n_tiles = tiles_x * tiles_y;                                                                                 \
         const int co_tiles = (g.Cout + 15) / 16, ci_groups = (g.Cin + Cfg::CIB - 1) / Cfg::CIB;                                \
