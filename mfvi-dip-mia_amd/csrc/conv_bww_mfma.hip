@@ -152,20 +152,39 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             }
         }
     };
-    auto mfma_tile = [&]() {             // k-steps of 4 consecutive pixels of one row, dealt round-robin to the MFMA waves
-        for (int ks = wv; ks < TH * (TW / 4); ks += NW) {
+    // k-steps of 4 consecutive pixels of one row, dealt round-robin to the MFMA waves.  The operands of k-step i+1 are read
+    // from LDS into a second register set while the matrix core works through the NB*KK MFMAs of k-step i.
+    auto mfma_tile = [&]() {
+        constexpr int NKS = TH * (TW / 4), NOP = NB * KK;
+        float a[2], bq[2][NOP];
+        auto load = [&](int ks, float& aa, float (&bb)[NOP]) {
             const int row = ks / (TW / 4), c4 = (ks % (TW / 4)) * 4;
-            const float a = s_g[l15 * GPLANE + row * TW + c4 + l4];
+            aa = s_g[l15 * GPLANE + row * TW + c4 + l4];
             const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * WV + (c4 + l4) * STRIDE + XOFF;
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx)
-                        acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[b * 16 * XPLANE + ky * WV + kx], acc[b][ky * KS + kx], 0, 0, 0);
-            if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a, 1.0f, accb, 0, 0, 0);
+                    for (int kx = 0; kx < KS; ++kx) bb[b * KK + ky * KS + kx] = xb[b * 16 * XPLANE + ky * WV + kx];
+        };
+        auto fma_all = [&](float aa, const float (&bb)[NOP]) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < KK; ++q) acc[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[b * KK + q], acc[b][q], 0, 0, 0);
+            if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, 1.0f, accb, 0, 0, 0);
+        };
+        int ks = wv;
+        if (ks >= NKS) return;
+        load(ks, a[0], bq[0]);
+        for (; ks + NW < NKS; ks += 2 * NW) {
+            load(ks + NW, a[1], bq[1]);
+            fma_all(a[0], bq[0]);
+            if (ks + 2 * NW < NKS) load(ks + 2 * NW, a[0], bq[0]);
+            fma_all(a[1], bq[1]);
         }
+        if (ks < NKS) fma_all(a[0], bq[0]);
     };
 
     const int tile_begin = bx * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
