@@ -380,7 +380,8 @@ int mfvi_gaussian_nll(const float* out, const float* target, int n, int H, int W
     if (n < 1 || factor < 1 || H % factor || W % factor) { set_error("gaussian_nll: bad shape n=%d H=%d W=%d factor=%d", n, H, W, factor); return -1; }
     if (dout && factor > 1) { hipError_t e = hipMemsetAsync(dout, 0, sizeof(float) * (size_t)n * 2 * H * W, st); if (e) return (int)e; }
     const long long npix = (long long)(H / factor) * (W / factor);
-    hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nblocks(npix, 256), n), dim3(256), 0, st, out, target, H, W, factor, grad_scale, dout, nll_sum);
+    // few blocks per sample: every block ends in one fp64 atomic on the SAME address, and those serialise (~0.2 us each)
+    hipLaunchKernelGGL(gaussian_nll_kernel, dim3(nblocks(npix, 16), n), dim3(256), 0, st, out, target, H, W, factor, grad_scale, dout, nll_sum);
     return (int)hipGetLastError();
 }
 
@@ -390,7 +391,7 @@ int mfvi_gaussian_nll_inpainting(const float* out, const float* target, const fl
     if (!out || !target || !mask || !nll_sum || n < 1 || H < 1 || W < 1 || (mask_channels != 1 && mask_channels != 3)) {
         set_error("gaussian_nll_inpainting: bad arguments (n=%d H=%d W=%d mask_channels=%d)", n, H, W, mask_channels); return -1; }
     const long long HW = (long long)H * W;
-    hipLaunchKernelGGL(gaussian_nll_inp_kernel, dim3(nblocks(HW, 256), n), dim3(256), 0, (hipStream_t)stream, out, target, mask, mask_channels, HW,
+    hipLaunchKernelGGL(gaussian_nll_inp_kernel, dim3(nblocks(HW, 16), n), dim3(256), 0, (hipStream_t)stream, out, target, mask, mask_channels, HW,
                        grad_scale, dout, nll_sum);
     return (int)hipGetLastError();
 }
@@ -401,7 +402,7 @@ int mfvi_kl(const float* mu, const float* rho, int64_t n, float prior_mu, float 
     if (n < 0 || !(prior_sigma > 0.f)) { set_error("kl: bad arguments"); return -1; }
     hipError_t e = hipMemsetAsync(kl_out, 0, sizeof(double), st); if (e) return (int)e;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(kl_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, st, mu, rho, (long long)n, prior_mu, prior_sigma, kl_out);
+    hipLaunchKernelGGL(kl_kernel, dim3(nblocks(n, 96)), dim3(256), 0, st, mu, rho, (long long)n, prior_mu, prior_sigma, kl_out);
     return (int)hipGetLastError();
 }
 
@@ -455,7 +456,7 @@ int mfvi_sq_err_sum(const float* a, const float* b, int64_t n, double* sum_out, 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sum_out, 0, sizeof(double), st); if (e) return (int)e;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(sq_err_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, a, b, (long long)n, sum_out);
+    hipLaunchKernelGGL(sq_err_kernel, dim3(nblocks(n, 32)), dim3(256), 0, st, a, b, (long long)n, sum_out);
     return (int)hipGetLastError();
 }
 
@@ -466,7 +467,7 @@ int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum
     SsimWin win; float s = 0.f;
     for (int i = 0; i < 11; ++i) { win.g[i] = expf(-(float)((i - 5) * (i - 5)) / (2.f * 1.5f * 1.5f)); s += win.g[i]; }
     for (int i = 0; i < 11; ++i) win.g[i] /= s;
-    hipLaunchKernelGGL(ssim_kernel, dim3(nblocks((long long)H * W, 1024)), dim3(256), 0, st, a, b, H, W, win, ssim_sum);
+    hipLaunchKernelGGL(ssim_kernel, dim3(nblocks((long long)H * W, 128)), dim3(256), 0, st, a, b, H, W, win, ssim_sum);
     return (int)hipGetLastError();
 }
 

@@ -45,12 +45,12 @@ rep('''            __syncthreads();                                             
                 mfma_tile();
                 TICK(5)
             }''')
-rep("    // ---- sum the waves through LDS.", "    TICK(6)\n    // ---- sum the waves through LDS.")
-rep('''    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = s_db[t];
-}''', '''    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = s_db[t];
+rep("    // ---- sum the MFMA waves through LDS", "    TICK(6)\n    // ---- sum the MFMA waves through LDS")
+rep("""    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = (s_db[t] + s_db[16 + t]) + (s_db[32 + t] + s_db[48 + t]);
+}""", """    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = (s_db[t] + s_db[16 + t]) + (s_db[32 + t] + s_db[48 + t]);
     TICK(7)
     if (prof && bx == 1 && by == 0 && k == 3 && lane == 0) for (int i = 0; i < 8; ++i) prof[wv * 8 + i] = T[i];
-}''')
+}""")
 rep("ci_groups, strips, co_tiles * ci_groups, n_samples);            \\", "ci_groups, strips, co_tiles * ci_groups, n_samples, prof);      \\\n        if (prof) { long long h[64]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost); fprintf(stderr, \"BWW ks %d s %d nb %d nt %d spec %d strips %d tpb %d\\n\", KS_, S_, NB_, NT_, (int)SP_, strips, tpb); for (int w = 0; w < NT_ / 64; ++w) { fprintf(stderr, \"wave %d:\", w); for (int i = 0; i < 8; ++i) fprintf(stderr, \" %lld\", h[w * 8 + i]); fprintf(stderr, \"\\n\"); } } \\")
 rep("    int cfg = g.tune[2] ? g.tune[2] : env_tune_w();", "    static long long* prof = [] { long long* p = nullptr; if (getenv(\"MFVI_PROF\")) { (void)hipMalloc((void**)&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();\n    int cfg = g.tune[2] ? g.tune[2] : env_tune_w();")
 rep("#include <cstdlib>", "#include <cstdlib>\n#include <cstdio>")
