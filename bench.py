@@ -84,11 +84,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # MFVI_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks on ONE GPU (RCCL refuses duplicate devices); the
+    # driver's runs use the default: one rank per GPU over RCCL
+    backend = os.environ.get("MFVI_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)          # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)         # "nccl" is RCCL on ROCm
 
     import mfvi_dip_mia_amd as M
     from mfvi_dip_mia_amd.engine import ElboEngine
