@@ -651,6 +651,9 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
                 if (OW > 130) return -3;
                 if ((th & 127) == 16) { if (OH * OW >= 256) GO_MF_FLAT(mf, 16) return -3; }
                 if ((th & 127) == 8) { GO_MF_FLAT(mf, 8) if (mf == 4) GO_(4, 8, true) }
+                // 128- and 64-pixel tiles for the 8x8 / 10x10 maps at the bottom of the hour-glass (a 256-pixel tile is 25-39% full there)
+                if ((th & 127) == 4) { if (mf == 1) GO_(1, 4, true) if (mf == 2) GO_(2, 4, true) if (mf == 4) GO_(4, 4, true) }
+                if ((th & 127) == 2) { if (mf == 1) GO_(1, 2, true) if (mf == 2) GO_(2, 2, true) if (mf == 4) GO_(4, 2, true) }
             }
             return -3;
         }

@@ -554,7 +554,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const
             // candidate tilings: fwd / bwd-data (mf, th, T) = fragments x tile rows x tiles per block;
             //                    bwd-weight (nb, waves, target/256) = input tiles per block x waves x block-count target
             std::vector<int> cands;
-            if (which < 2) { for (int th : {8, 16, 8 | 128, 16 | 128}) for (int mf = 1; mf <= 4; ++mf) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | th << 8 | T << 16); }
+            if (which < 2) { for (int th : {8, 16, 8 | 128, 16 | 128, 4 | 128, 2 | 128}) for (int mf = 1; mf <= 4; ++mf) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | th << 8 | T << 16); }
             else { for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16); }
             int best = 0; float best_ms = 1e30f;
             for (int cand : cands) {

@@ -1,5 +1,8 @@
 set -e
 mkdir -p gpurun_out
-export MFVI_BENCH_BACKEND=gloo
-timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_g2.log 2>&1 || { tail -30 gpurun_out/bench_g2.log; exit 1; }
-tail -2 gpurun_out/bench_g2.log | cut -c1-700
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest.log 2>&1 || { tail -70 gpurun_out/pytest.log; exit 1; }
+tail -3 gpurun_out/pytest.log
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-all > gpurun_out/bench_at.log 2>&1
+tail -1 gpurun_out/bench_at.log | cut -c1-300
+MFVI_PROFILE_FULL=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-all > gpurun_out/bench_ops.log 2>&1
+grep -E "^op (10|11|13|14|16) " gpurun_out/bench_ops.log

@@ -373,7 +373,7 @@ def test_tilings_do_not_change_results(M, shape):
     lib = M._lib.lib()
     ref = _run_plan(plan, P, seed, n, z, dout)
     enc = lambda a, b, c: a | b << 8 | c << 16
-    fwd_bwd = [(1, 8, 1), (1, 16, 1), (2, 8, 2), (3, 8, 1), (1, 8 | 128, 1), (1, 16 | 128, 1), (2, 8 | 128, 2)]
+    fwd_bwd = [(1, 8, 1), (1, 16, 1), (2, 8, 2), (3, 8, 1), (1, 8 | 128, 1), (1, 16 | 128, 1), (2, 8 | 128, 2), (1, 4 | 128, 1), (2, 2 | 128, 1), (4, 4 | 128, 1)]
     bww = [(1, 4, 1), (1, 8, 2), (2, 9, 1), (3, 9, 1), (3, 4, 2)]
     for which, cands in ((0, fwd_bwd), (1, fwd_bwd), (2, bww)):
         for cand in cands:
