@@ -647,6 +647,12 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         const int mf = forced & 255, th = (forced >> 8) & 255;
         forced_T = (forced >> 16) & 255;
         if (th & 128) {        // FLAT tiles: 3x3 stride-1 kernels on domains up to 130 wide
+            if constexpr (KS == 3 && STRIDE == 2) {      // stride-2 forward on small outputs (MODE 1 always runs the stride-1 kernel)
+                if (OW > 32) return -3;
+                if ((th & 127) == 8) { if (mf == 1) GO_(1, 8, true) if (mf == 2) GO_(2, 8, true) if (mf == 4) GO_(4, 8, true) }
+                if ((th & 127) == 4) { if (mf == 1) GO_(1, 4, true) if (mf == 2) GO_(2, 4, true) if (mf == 4) GO_(4, 4, true) }
+                if ((th & 127) == 2) { if (mf == 1) GO_(1, 2, true) if (mf == 2) GO_(2, 2, true) if (mf == 4) GO_(4, 2, true) }
+            }
             if constexpr (KS == 3 && STRIDE == 1) {
                 if (OW > 130) return -3;
                 if ((th & 127) == 16) { if (OH * OW >= 256) GO_MF_FLAT(mf, 16) return -3; }
