@@ -154,11 +154,15 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     };
     // k-steps of 4 consecutive pixels of one row, dealt round-robin to the MFMA waves.  The operands of k-step i+1 are read
     // from LDS into a second register set while the matrix core works through the NB*KK MFMAs of k-step i.
-    auto mfma_tile = [&]() {
-        constexpr int NKS = TH * (TW / 4), NOP = NB * KK;
+    // Only the k-steps that touch pixels inside the map are issued (dy is zero outside): on the 8x8 / 16x16 maps at the bottom
+    // of the hour-glass that is 1/4 / 1/2 of the 8 x 32 tile.
+    auto mfma_tile = [&](int tile) {
+        constexpr int NOP = NB * KK;
+        const int vr = min(TH, Ho - (tile / tiles_x) * TH), vc4 = (min(TW, Wo - (tile % tiles_x) * TW) + 3) >> 2;
+        const int NKS = vr * vc4;
         float a[2], bq[2][NOP];
         auto load = [&](int ks, float& aa, float (&bb)[NOP]) {
-            const int row = ks / (TW / 4), c4 = (ks % (TW / 4)) * 4;
+            const int row = ks / vc4, c4 = (ks - row * vc4) * 4;
             aa = s_g[l15 * GPLANE + row * TW + c4 + l4];
             const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * WV + (c4 + l4) * STRIDE + XOFF;
 #pragma unroll
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             for (int tile = tile_begin; tile < tile_end; ++tile) {
                 if (tile > tile_begin) __syncthreads();                  // (B1)
                 __syncthreads();                                         // (B2)
-                mfma_tile();
+                mfma_tile(tile);
             }
         }
     } else {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             stage();
             __syncthreads();
             if (tile + 1 < tile_end) prefetch(tile + 1);
-            mfma_tile();
+            mfma_tile(tile);
         }
     }
 
