@@ -203,7 +203,15 @@ class MeanFieldVI(nn.Module):
             raise NotImplementedError("module pattern outside the skip() family: " + what)
 
         def run(m, v):
-            # v = dict(tid, pad, up): pending ReflectionPad2d amount / pending x2 bilinear upsample
+            # v = dict(tid, pad, up): pending ReflectionPad2d amount / pending x2 upsample (None or its mode)
+            def flush_up(v):
+                """A pending Upsample with no Concat after it (skip() with num_channels_skip == 0): materialise it."""
+                if v['up']:
+                    t = P.tensors[v['tid']]
+                    out = P.tensor(t['C'], 2 * t['H'], 2 * t['W'])
+                    P.concat_up(None, v['tid'], out, v['up'])
+                    v = dict(tid=out, pad=0, up=None)
+                return v
             if isinstance(m, nn.Sequential):
                 for c in m._modules.values():
                     v = run(c, v)
@@ -217,8 +225,8 @@ class MeanFieldVI(nn.Module):
                     fail("Concat expects (skip branch, up-sampled deeper branch)")
                 ta, tb = P.tensors[a['tid']], P.tensors[b['tid']]
                 out = P.tensor(ta['C'] + tb['C'], 2 * tb['H'], 2 * tb['W'])
-                P.concat_up(a['tid'], b['tid'], out)
-                return dict(tid=out, pad=0, up=False)
+                P.concat_up(a['tid'], b['tid'], out, b['up'])
+                return dict(tid=out, pad=0, up=None)
             if isinstance(m, nn.ReflectionPad2d):
                 p = m.padding
                 if len(set(p)) != 1:
@@ -232,16 +240,19 @@ class MeanFieldVI(nn.Module):
                 k = m.kernel_size[0]
                 if m.kernel_size[0] != m.kernel_size[1] or v['pad'] != k // 2 or v['up']:
                     fail("Conv2d must follow ReflectionPad2d(k//2)")
+                if k not in (1, 3, 5):
+                    fail("kernel size %d (1, 3, 5 are built)" % k)
                 stride = m.kwargs['stride'][0] if isinstance(m.kwargs['stride'], (tuple, list)) else m.kwargs['stride']
                 out = P.tensor(m.out_channels, *P.conv_out_hw(v['tid'], k, stride))
                 P.conv(v['tid'], out, k, stride, bias=m._has_bias)
                 lay = P.layers[-1]
                 if lay['w_off'] != m._w_off or lay['b_off'] != m._b_off:
                     fail("internal: parameter offsets out of sync")
-                return dict(tid=out, pad=0, up=False)
+                return dict(tid=out, pad=0, up=None)
             if isinstance(m, nn.BatchNorm2d):
-                if v['pad'] or v['up']:
-                    fail("BatchNorm2d after a pending pad/upsample")
+                v = flush_up(v)
+                if v['pad']:
+                    fail("BatchNorm2d after a pending pad")
                 P.set_bn(v['tid'], act=False, eps=m.eps)
                 if P.bns[-1]['off'] != m._bn_off:
                     fail("internal: BatchNorm offsets out of sync")
@@ -253,14 +264,14 @@ class MeanFieldVI(nn.Module):
                 t['has_act'], t['slope'] = 1, float(m.negative_slope)
                 return v
             if isinstance(m, nn.Upsample):
-                if m.mode != 'bilinear' or float(m.scale_factor) != 2.0 or m.align_corners:
-                    raise NotImplementedError("Upsample(mode=%r, scale=%r): only bilinear x2 (align_corners=False) is built" % (m.mode, m.scale_factor))
+                if m.mode not in ('bilinear', 'nearest') or float(m.scale_factor) != 2.0 or m.align_corners:
+                    raise NotImplementedError("Upsample(mode=%r, scale=%r): only bilinear / nearest x2 (align_corners=False) are built" % (m.mode, m.scale_factor))
                 if v['pad'] or v['up']:
                     fail("Upsample after a pending pad/upsample")
-                return dict(v, up=True)
+                return dict(v, up=m.mode)
             fail(type(m).__name__)
 
-        res = run(self.net, dict(tid=zin, pad=0, up=False))
+        res = run(self.net, dict(tid=zin, pad=0, up=None))
         if res['pad'] or res['up'] or P.tensors[res['tid']]['has_bn']:
             fail("the net must end with a convolution")
         if P.n_vi != self.n_vi or P.n_bn != self.n_bn:

@@ -66,25 +66,24 @@ def skip(num_input_channels=2, num_output_channels=3,
             raise NotImplementedError("dropout layers belong to the MC-dropout baselines, not to the MFVI path")
     if need_sigmoid:
         raise NotImplementedError("need_sigmoid=True is not used by the MFVI runners (models/__init__.py:4)")
-    if not need1x1_up:
-        raise NotImplementedError("need1x1_up=False is not part of the MFVI runners' net")
+    step = 2 if need1x1_up else 1          # 'up' convolutions per scale: the reference's running counter for the names
 
     def per_scale(v):
         return list(v) if isinstance(v, (list, tuple)) else [v] * n_scales
     up_modes, down_modes = per_scale(upsample_mode), per_scale(downsample_mode)
     fdown, fup = per_scale(filter_size_down), per_scale(filter_size_up)
 
+    def add(seq, name, module):
+        """add_module with the reference's collision rule: a second 'X_up_n' in the same container becomes 'X_up_n_1'."""
+        if name in seq._modules:
+            name += '_1'
+        seq.add_module(name, module)
+
     def build_scale(i, cin, seq):
         """Fill `seq` (the reference's model_tmp) with scale i; returns nothing."""
-        n_up = 2 * (n_scales - i) - 1                      # 9, 7, 5, 3, 1
+        n_up = step * (n_scales - i) - 1                   # 9, 7, 5, 3, 1  (need1x1_up=False: 4, 3, 2, 1, 0)
         n_deep = 2 * i + 1                                 # 1, 3, 5, 7, 9
         ns, nd, nu = num_channels_skip[i], num_channels_down[i], num_channels_up[i]
-        if ns == 0:
-            raise NotImplementedError("num_channels_skip=0 (no skip branch) is not part of the MFVI runners' net")
-        sk = nn.Sequential()
-        sk.add_module('Sequential_skip_%d' % (i + 1), _conv_block(cin, ns, filter_skip_size, 1, need_bias, pad, 'stride', 'skip', i + 1))
-        sk.add_module('BatchNorm2d_skip_%d' % (i + 1), nn.BatchNorm2d(ns))
-        sk.add_module('LeakyReLU_skip_%d' % (i + 1), _act(act_fun))
         dp = nn.Sequential()
         dp.add_module('Sequential_deeper_%d' % n_deep, _conv_block(cin, nd, fdown[i], 2, need_bias, pad, down_modes[i], 'deeper', n_deep))
         dp.add_module('BatchNorm2d_deeper_%d' % n_deep, nn.BatchNorm2d(nd))
@@ -101,18 +100,26 @@ def skip(num_input_channels=2, num_output_channels=3,
         else:
             dp.add_module('7', nn.Upsample(scale_factor=2, mode=up_modes[i]))
             k_in = nd
-        seq.add_module('Concat_up_%d' % n_up, Concat(1, sk, dp))
-        seq.add_module('BatchNorm2d_up_%d' % n_up, nn.BatchNorm2d(ns + k_in))
-        seq.add_module('Sequential_up_%d' % n_up, _conv_block(ns + k_in, nu, fup[i], 1, need_bias, pad, 'stride', 'up', n_up))
-        seq.add_module('BatchNorm2d_up_%d_1' % n_up, nn.BatchNorm2d(nu))
-        seq.add_module('LeakyReLU_up_%d' % n_up, _act(act_fun))
-        seq.add_module('Sequential_up_%d' % (n_up + 1), _conv_block(nu, nu, 1, 1, need_bias, pad, 'stride', 'up', n_up + 1))
-        seq.add_module('BatchNorm2d_up_%d' % (n_up + 1), nn.BatchNorm2d(nu))
-        seq.add_module('LeakyReLU_up_%d' % (n_up + 1), _act(act_fun))
+        if ns != 0:
+            sk = nn.Sequential()
+            sk.add_module('Sequential_skip_%d' % (i + 1), _conv_block(cin, ns, filter_skip_size, 1, need_bias, pad, 'stride', 'skip', i + 1))
+            sk.add_module('BatchNorm2d_skip_%d' % (i + 1), nn.BatchNorm2d(ns))
+            sk.add_module('LeakyReLU_skip_%d' % (i + 1), _act(act_fun))
+            add(seq, 'Concat_up_%d' % n_up, Concat(1, sk, dp))
+        else:                                              # models/skip.py:62-66: no skip branch, the deeper path is added as is
+            add(seq, 'Sequential_up_%d' % n_up, dp)
+        add(seq, 'BatchNorm2d_up_%d' % n_up, nn.BatchNorm2d(ns + k_in))
+        add(seq, 'Sequential_up_%d' % n_up, _conv_block(ns + k_in, nu, fup[i], 1, need_bias, pad, 'stride', 'up', n_up))
+        add(seq, 'BatchNorm2d_up_%d' % n_up, nn.BatchNorm2d(nu))
+        add(seq, 'LeakyReLU_up_%d' % n_up, _act(act_fun))
+        if need1x1_up:
+            add(seq, 'Sequential_up_%d' % (n_up + 1), _conv_block(nu, nu, 1, 1, need_bias, pad, 'stride', 'up', n_up + 1))
+            add(seq, 'BatchNorm2d_up_%d' % (n_up + 1), nn.BatchNorm2d(nu))
+            add(seq, 'LeakyReLU_up_%d' % (n_up + 1), _act(act_fun))
 
     model = nn.Sequential()
     build_scale(0, num_input_channels, model)
-    model.add_module(str(len(model) + 1), _conv_block(num_channels_up[0], num_output_channels, 1, 1, need_bias, pad, 'stride', 'up', 2 * n_scales + 1))
+    model.add_module(str(len(model) + 1), _conv_block(num_channels_up[0], num_output_channels, 1, 1, need_bias, pad, 'stride', 'up', step * n_scales + 1))
     return model
 
 

@@ -176,3 +176,39 @@ def test_inpainting_net_against_reference_golden(M, golden_dir):
     plan.backward(d_mu, d_rho, d_bn, d_z, seed, 4, 0, 1, dout, dmu, drho, dbn, dz=dz)
     for got, key in ((dmu, "net_dmu"), (drho, "net_drho"), (dbn, "net_dbn"), (dz[0], "net_dz")):
         assert relerr(got.cpu().numpy(), g[key]) < 2e-3, key              # fp32 reference, LeakyReLU kinks over 3x3 maps
+
+
+def test_inpainting_dropin_wrapper_matches_reference_golden(M, golden_dir):
+    """The reference's calling sequence for inpainting (bayesian_optimization.py:2970-3040) on the drop-in classes: skip(...) with
+    the runner's options -> MeanFieldVI -> out[:, :3].sigmoid() + masked NLL -> backward, against the reference's own run."""
+    import os
+    from mfvi_dip_mia_amd.nets import skip
+    g = np.load(os.path.join(golden_dir, "inpainting.npz"), allow_pickle=False)
+    H = W = 24; seed = 21
+    net = skip(8, num_output_channels=4, pad='reflection', num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
+               num_channels_skip=[0, 0, 0], filter_size_down=5, filter_size_up=3, filter_skip_size=1, need1x1_up=False,
+               upsample_mode='nearest', need_sigmoid=False)
+    net = M.MeanFieldVI(net, prior={'mu': 0.0, 'sigma': 0.1}, replace_layers='all', device=torch.device('cuda'), reparam='', seed=seed)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["net_keys"]]
+    P, _, _, _ = M.program.skip_program(H, W, input_depth=8, n_out=4, nd=(8, 16, 16), nu=(8, 16, 16), ns=(0, 0, 0), fd=5, fu=3,
+                                        need1x1_up=False, upsample_mode="nearest")
+    mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, P.n_vi); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, P.n_vi)
+    gg = O.normal_fill(seed, 2, 7, 0, 0, P.n_bn); bn = np.zeros(P.n_bn, np.float32)
+    for b in P.bns:
+        c, off = b["C"], b["off"]
+        bn[off:off + c] = 1.0 + 0.1 * gg[off:off + c]; bn[off + c:off + 2 * c] = 0.1 * gg[off + c:off + 2 * c]
+    with torch.no_grad():                       # the flat buffer IS the parameters (views): same layout as the layer program
+        net._flat[:P.n_vi].copy_(dev(mu)); net._flat[P.n_vi:2 * P.n_vi].copy_(dev(rho)); net._flat[2 * P.n_vi:].copy_(dev(bn))
+    net._step = 4                               # the golden drew eps at step 4, sample 0
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, 8 * H * W).reshape(1, 8, H, W)).requires_grad_(True)
+    tgt = dev(O.uniform_fill(312, 1, 0, 0, 3 * H * W).reshape(1, 3, H, W))
+    mask = dev((O.uniform_fill(312, 2, 0, 0, H * W).reshape(1, 1, H, W) > 0.25).astype(np.float32))
+    out = net(z)
+    assert relerr(out[0].detach().cpu().numpy(), g["net_out"]) < 1e-4
+    s = torch.clamp(out[:, 3:], -20, 20)
+    nll = ((torch.exp(s) * (tgt - out[:, :3].sigmoid()) ** 2 - s) * mask).mean()
+    assert abs(float(nll) - float(g["net_nll"])) < 1e-4 * max(abs(float(g["net_nll"])), 1e-2)
+    nll.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert relerr(z.grad[0].cpu().numpy(), g["net_dz"]) < 2e-3
+    assert torch.isfinite(grads).all()

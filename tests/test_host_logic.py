@@ -122,3 +122,23 @@ def test_k_sharding_two_gloo_ranks(tmp_path):
     full = np.concatenate([r["dmu"], r["drho"], r["dbn"]])
     assert np.abs(a["g"][:full.size] - full).max() < 1e-5 * np.abs(full).max()
     assert abs(a["g"][full.size] - r["nll"]) < 1e-5 * abs(r["nll"])
+
+
+def test_inpainting_skip_builder_matches_reference_state_dict_keys(golden_dir):
+    """skip() with the inpainting runner's options (no skip branches, need1x1_up=False: bayesian_optimization.py:2970-2998) gets
+    the reference's module names too, including its 'Sequential_up_n' / 'Sequential_up_n_1' collision suffixes."""
+    from mfvi_dip_mia_amd.nets import skip
+    g = np.load(os.path.join(golden_dir, "inpainting.npz"))
+    ref = [str(k) for k in g["net_keys"]]
+    net = skip(8, num_output_channels=4, pad='reflection', num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
+               num_channels_skip=[0, 0, 0], filter_size_down=5, filter_size_up=3, filter_skip_size=1, need1x1_up=False,
+               upsample_mode='nearest', need_sigmoid=False)
+    mine = []
+    for k in net.state_dict().keys():
+        if k.endswith(".weight") and "Conv2d" in k:
+            mine += ["net." + k[:-6] + s for s in ("W_mu", "W_rho")]
+        elif k.endswith(".bias") and "Conv2d" in k:
+            mine += ["net." + k[:-4] + s for s in ("bias_mu", "bias_rho")]
+        else:
+            mine.append("net." + k)
+    assert mine == ref
