@@ -154,6 +154,12 @@ int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum
  * (slot pointers may be NULL).  C = 2 (den/SR) or 1 (CT: no aleatoric channel). */
 int mfvi_bookkeep(const float* out, int n, int C, int H, int W, float* ema, float ema_weight, int first, float* out_clip,
                   float* ale_clip, float* avg_clip, float* ring_epi_slot, float* ring_ale_slot, void* stream);
+/* The same pass for the inpainting runner (bayesian_optimization.py:3039-3064): out[n][4][H][W] = 3 colour logits + 1 log-precision;
+ * m = mean_k sigmoid(out[k][:3]), a = mean_k exp(-out[k][3]); ema[4][HW]; out_clip[3][HW], ale_clip[HW], avg_clip[3][HW] clipped to
+ * [0,1]; masked copies (x * mask, mask[mask_channels][HW]) of img, out_clip and avg_clip for the masked PSNR/SSIM; ring slots [3][HW] / [HW]. */
+int mfvi_bookkeep_inpainting(const float* out, int n, int H, int W, const float* img, const float* mask, int mask_channels, float* ema,
+                             float ema_weight, int first, float* out_clip, float* ale_clip, float* avg_clip, float* img_masked,
+                             float* out_masked, float* avg_masked, float* ring_epi_slot, float* ring_ale_slot, void* stream);
 /* torch.var(ring, dim=0) (unbiased) / torch.mean(ring, dim=0) over R ring-buffer slots (bayesian_optimization.py:1412-1413) */
 int mfvi_ring_stats(const float* ring, int R, int H, int W, float* var_out, float* mean_out, void* stream);
 /* post-step output handling: mean[n][HW] kept, out[:,1] <- exp(-out[:,1]); ema = ema*w + out*(1-w) (first: copy) */

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mfvi_sq_err_sum": (_I, [_P, _P, _I64, _P, _P]),
     "mfvi_ssim_sum": (_I, [_P, _P, _I, _I, _P, _P]),
     "mfvi_bookkeep": (_I, [_P, _I, _I, _I, _I, _P, _F, _I, _P, _P, _P, _P, _P, _P]),
+    "mfvi_bookkeep_inpainting": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mfvi_ring_stats": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mfvi_post_step": (_I, [_P, _I, _I, _I, _I, _P, _F, _I, _P]),
     "mfvi_last_error": (C.c_char_p, []),

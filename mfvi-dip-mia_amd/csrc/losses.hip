@@ -217,6 +217,38 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(const float* __restrict__
     }
 }
 
+
+// inpainting runner bookkeeping (bayesian_optimization.py:3039-3064): colour channels through the sigmoid, masked copies for the metrics
+__global__ __launch_bounds__(256) void bookkeep_inp_kernel(const float* __restrict__ out, int n, long long HW, const float* __restrict__ img,
+                                                           const float* __restrict__ mask, int mask_channels, float* __restrict__ ema, float w,
+                                                           int first, float* __restrict__ out_clip, float* __restrict__ ale_clip,
+                                                           float* __restrict__ avg_clip, float* __restrict__ img_masked,
+                                                           float* __restrict__ out_masked, float* __restrict__ avg_masked,
+                                                           float* __restrict__ ring_epi, float* __restrict__ ring_ale)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int k = 0; k < n; ++k) a += expf(-out[((long long)k * 4 + 3) * HW + i]);
+        a /= (float)n;
+        ema[3 * HW + i] = first ? a : ema[3 * HW + i] * w + a * (1.f - w);
+        const float ac = fminf(fmaxf(a, 0.f), 1.f);
+        ale_clip[i] = ac; if (ring_ale) ring_ale[i] = ac;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float m = 0.f;
+            for (int k = 0; k < n; ++k) m += sigmoid_f(out[((long long)k * 4 + c) * HW + i]);
+            m /= (float)n;
+            const float e0 = first ? m : ema[c * HW + i] * w + m * (1.f - w);
+            ema[c * HW + i] = e0;
+            const float mc = fminf(fmaxf(m, 0.f), 1.f), ec = fminf(fmaxf(e0, 0.f), 1.f);
+            const float mk = mask[(mask_channels == 3 ? c : 0) * HW + i];
+            out_clip[c * HW + i] = mc; avg_clip[c * HW + i] = ec;
+            if (ring_epi) ring_epi[c * HW + i] = mc;
+            img_masked[c * HW + i] = img[c * HW + i] * mk; out_masked[c * HW + i] = mc * mk; avg_masked[c * HW + i] = ec * mk;
+        }
+    }
+}
+
 // torch.var(ring, dim=0) (unbiased) and torch.mean(ring, dim=0) over the R-slot ring buffers (bayesian_optimization.py:1412-1413)
 __global__ __launch_bounds__(256) void ring_stats_kernel(const float* __restrict__ ring, int R, long long HW, float* __restrict__ var_out,
                                                          float* __restrict__ mean_out)
@@ -478,6 +510,18 @@ int mfvi_bookkeep(const float* out, int n, int C, int H, int W, float* ema, floa
     const long long HW = (long long)H * W;
     hipLaunchKernelGGL(bookkeep_kernel, dim3(nblocks(HW)), dim3(256), 0, (hipStream_t)stream, out, n, C, HW, ema, ema_weight, first, out_clip,
                        ale_clip, avg_clip, ring_epi_slot, ring_ale_slot);
+    return (int)hipGetLastError();
+}
+
+int mfvi_bookkeep_inpainting(const float* out, int n, int H, int W, const float* img, const float* mask, int mask_channels, float* ema,
+                             float ema_weight, int first, float* out_clip, float* ale_clip, float* avg_clip, float* img_masked,
+                             float* out_masked, float* avg_masked, float* ring_epi_slot, float* ring_ale_slot, void* stream)
+{
+    if (n < 1 || !out || !img || !mask || !ema || !out_clip || !ale_clip || !avg_clip || !img_masked || !out_masked || !avg_masked ||
+        (mask_channels != 1 && mask_channels != 3)) { set_error("bookkeep_inpainting: bad arguments"); return -1; }
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(bookkeep_inp_kernel, dim3(nblocks(HW)), dim3(256), 0, (hipStream_t)stream, out, n, HW, img, mask, mask_channels, ema,
+                       ema_weight, first, out_clip, ale_clip, avg_clip, img_masked, out_masked, avg_masked, ring_epi_slot, ring_ale_slot);
     return (int)hipGetLastError();
 }
 

@@ -198,6 +198,97 @@ def run_ct_mfvi(img="phantom", imsize=(256, 256), num_iter=5000, lr=3e-4, temp=4
     return _run("ct", img, imsize, 0.0, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, **kw)
 
 
+def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=2e-3, temp=4e-6, sigma=0.01, input_depth=32, seed=42,
+                 show_every=100, plot=False, save=True, save_path="../logs", K=1, net_kwargs=None, verbose=False, **unused):
+    """bayesian_optimization.py:2892-3114: inpainting with the 6-scale no-skip net (5x5 down filters, nearest up-sampling), sigmoid on
+    the colour channels, masked Gaussian NLL.  img: (3, H, W) array in [0, 1] or 'phantom' (three synthetic planes); mask: (1|3, H, W),
+    1 = known pixel (the reference ships its masks in data/inpainting/).  save.npz carries the reference's keys for this task
+    (img_inpainting, img_mask, mse_corrupted, mse_gt, recons, uncerts, uncerts_ale, psnrs, ssims)."""
+    import torch
+    timestamp = str(time.time())
+    run_dir = os.path.join(save_path, timestamp)
+    if save:
+        os.makedirs(run_dir, exist_ok=False)
+        with open(os.path.join(run_dir, "locals.txt"), "w") as f:
+            for key, val in dict(task="inp", imsize=imsize, num_iter=num_iter, lr=lr, temp=temp, sigma=sigma, input_depth=input_depth,
+                                 seed=seed, show_every=show_every, K=K, save_path=save_path).items():
+                print(key, "=", val, file=f)
+    if isinstance(img, np.ndarray):
+        img_np = np.ascontiguousarray(img, np.float32)
+    else:
+        img_np = np.stack([_load_image(img, imsize, seed + c) for c in range(3)]).astype(np.float32)
+    _, H, W = img_np.shape
+    if mask is None:                                                  # synthetic scratches: a seeded random-walk mask, ~12 % missing
+        rng = np.random.default_rng(seed)
+        mask = np.ones((1, H, W), np.float32)
+        for _ in range(24):
+            y, x = rng.integers(0, H), rng.integers(0, W)
+            for _ in range(H):
+                mask[0, max(y - 1, 0):y + 2, max(x - 1, 0):x + 2] = 0
+                y = int(np.clip(y + rng.integers(-1, 2), 0, H - 1)); x = int(np.clip(x + rng.integers(-1, 2), 0, W - 1))
+    mask_np = np.ascontiguousarray(mask, np.float32)
+    if mask_np.ndim == 2:
+        mask_np = mask_np[None]
+    num_iter += 1                                                     # bayesian_optimization.py:2935
+    eng = ElboEngine(H, W, task="inp", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=net_kwargs)
+    eng.set_target(torch.from_numpy(img_np), torch.from_numpy(mask_np))
+    dev = "cuda"; HW = H * W; mc = mask_np.shape[0]
+    ema = torch.zeros((4, H, W), device=dev)
+    out_clip = torch.zeros((3, H, W), device=dev); avg_clip = torch.zeros_like(out_clip); ale_clip = torch.zeros((H, W), device=dev)
+    img_m = torch.zeros_like(out_clip); out_m = torch.zeros_like(out_clip); avg_m = torch.zeros_like(out_clip)
+    ring_epi = torch.zeros((MC_ITER, 3, H, W), device=dev); ring_ale = torch.zeros((MC_ITER, H, W), device=dev)
+    metrics = torch.zeros((num_iter, 10, 3), dtype=torch.float64, device=dev)      # per channel: mse, 3 psnr-mse, 3 ssim sums (+ spare)
+    var = torch.zeros((3, H, W), device=dev); ale_mean = torch.zeros((H, W), device=dev)
+    n_snap = num_iter // show_every + 1
+    recons = np.zeros((n_snap, 3, H, W)); uncerts_epi = np.zeros((n_snap, 3, H, W)); uncerts_ale = np.zeros((n_snap, 1, H, W))
+    lib, p = L.lib(), L.ptr
+    img_d = eng.target
+    t0 = time.perf_counter()
+    for i in range(num_iter):
+        eng.step()
+        sp = L.stream_ptr(); slot = i % MC_ITER
+        L.check(lib.mfvi_bookkeep_inpainting(p(eng.out), eng.chunk, H, W, p(img_d), p(eng.mask), mc, p(ema), EXP_WEIGHT, int(i == 0), p(out_clip), p(ale_clip),
+                                             p(avg_clip), p(img_m), p(out_m), p(avg_m), p(ring_epi[slot]), p(ring_ale[slot]), sp))
+        m = metrics[i]
+        for c in range(3):                                            # channel-wise sums; means over the 3 channels taken on the host
+            L.check(lib.mfvi_sq_err_sum(p(ema[c]), p(img_d[c]), HW, p(m[0, c:]), sp))            # mse(out_avg[:, :3], img)        :3051-3052
+            L.check(lib.mfvi_sq_err_sum(p(img_d[c]), p(out_clip[c]), HW, p(m[1, c:]), sp))       # psnr_corrupted                  :3062
+            L.check(lib.mfvi_sq_err_sum(p(img_m[c]), p(out_m[c]), HW, p(m[2, c:]), sp))          # psnr_gt (masked)                :3063
+            L.check(lib.mfvi_sq_err_sum(p(img_m[c]), p(avg_m[c]), HW, p(m[3, c:]), sp))          # psnr_gt_sm
+            L.check(lib.mfvi_ssim_sum(p(img_d[c]), p(out_clip[c]), H, W, p(m[4, c:]), sp))
+            L.check(lib.mfvi_ssim_sum(p(img_m[c]), p(out_m[c]), H, W, p(m[5, c:]), sp))
+            L.check(lib.mfvi_ssim_sum(p(img_m[c]), p(avg_m[c]), H, W, p(m[6, c:]), sp))
+        if i % show_every == 0:
+            for c in range(3):
+                L.check(lib.mfvi_ring_stats(p(ring_epi[:, c].contiguous()), MC_ITER, H, W, p(var[c]), None, sp))
+            L.check(lib.mfvi_ring_stats(p(ring_ale), MC_ITER, H, W, None, p(ale_mean), sp))
+            uncerts_epi[i // show_every] = var.cpu().numpy(); uncerts_ale[i // show_every, 0] = ale_mean.cpu().numpy()
+            recons[i // show_every] = avg_clip.cpu().numpy()
+            if verbose:
+                nll, kl, loss = eng.losses()
+                print("iter %6d  loss %.5f  nll %.5f  kl %.4e  (%.1f it/s)" % (i, loss, nll, kl, (i + 1) / (time.perf_counter() - t0)))
+    torch.cuda.synchronize()
+    mt = metrics.cpu().numpy().mean(axis=2) / HW                      # mean over the colour channels == mean over all 3*H*W elements
+    mse_corrupted = mt[:, 0]; mse_gt = mt[:, 0]                       # the reference computes both against img_torch (:3051-3052)
+    with np.errstate(divide="ignore"):
+        psnrs = 10.0 * np.log10(1.0 / mt[:, 1:4])
+    ssims = mt[:, 4:7]
+    if save:
+        wrap = lambda a: {"mfvi": a}
+        np.savez(os.path.join(run_dir, "save.npz"), img_inpainting=img_np, img_mask=mask_np, mse_corrupted=wrap(mse_corrupted), mse_gt=wrap(mse_gt),
+                 recons=wrap(recons), uncerts=wrap(uncerts_epi), uncerts_ale=wrap(uncerts_ale), psnrs=wrap(psnrs), ssims=wrap(ssims))
+        with open(os.path.join(run_dir, "locals.txt"), "a") as f:
+            print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
+        if plot:
+            try:
+                from PIL import Image
+                Image.fromarray((np.clip(recons[-1].transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)).save(os.path.join(run_dir, "out_avg.png"))
+            except Exception:
+                pass
+    return dict(psnr=float(psnrs[-1, 2]), run_dir=run_dir if save else None, psnrs=psnrs, ssims=ssims, mse_corrupted=mse_corrupted, mse_gt=mse_gt,
+                recons=recons, uncerts=uncerts_epi, uncerts_ale=uncerts_ale, seconds=time.perf_counter() - t0, engine=eng)
+
+
 def load_config(path):
     """The reference's JSON schema {bo_params:{temp:{candidates}, sigma:{candidates}}, run_params:{...}}
     (bayesian_optimization.py:3901-3909 reads it through pandas; plain json is equivalent)."""
@@ -211,14 +302,14 @@ def load_config(path):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="denoising", choices=["denoising", "super-resolution", "ct"])
+    ap.add_argument("--task", default="denoising", choices=["denoising", "super-resolution", "ct", "inpainting"])
     ap.add_argument("--bayes", default="mfvi", choices=["mfvi"])
     ap.add_argument("--config", required=True)
     ap.add_argument("--img", default=None); ap.add_argument("--imsize", type=int, default=None)
     ap.add_argument("--k", type=int, default=1); ap.add_argument("--num-iter", type=int, default=None); ap.add_argument("--save-path", default=None)
     a = ap.parse_args(argv)
     cands, rp = load_config(a.config)
-    fn = {"denoising": run_den_mfvi, "super-resolution": run_sr_mfvi, "ct": run_ct_mfvi}[a.task]
+    fn = {"denoising": run_den_mfvi, "super-resolution": run_sr_mfvi, "ct": run_ct_mfvi, "inpainting": run_inp_mfvi}[a.task]
     if a.img is not None:
         rp["img"] = a.img
     if a.imsize:

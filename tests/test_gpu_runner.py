@@ -86,3 +86,23 @@ def test_runner_artifacts(M, tmp_path):
     r3 = M.runner.run_sr_mfvi(img="phantom", imsize=(64, 64), num_iter=4, lr=1e-3, temp=4.4e-7, sigma=4.9e-8, input_depth=8, seed=2, show_every=2,
                               save=False, K=2, net_kwargs=SMALL)
     assert np.isfinite(r3["psnrs"]).all()
+
+
+def test_inpainting_runner_artifacts(M, tmp_path):
+    """run_inp_mfvi (bayesian_optimization.py:2892-3114): save.npz carries the reference's keys for this task; the masked PSNR of the
+    smoothed reconstruction improves over the run; device bookkeeping == numpy on the final state."""
+    from mfvi_dip_mia_amd.runner import run_inp_mfvi
+    r = run_inp_mfvi(img="phantom", imsize=(192, 192), num_iter=60, lr=2e-3, temp=1e-12, sigma=6.5e-4, input_depth=16, seed=2, show_every=20,
+                     plot=True, save=True, save_path=str(tmp_path), K=1)
+    z = np.load(os.path.join(r["run_dir"], "save.npz"), allow_pickle=True)
+    assert set(z.files) == {"img_inpainting", "img_mask", "mse_corrupted", "mse_gt", "recons", "uncerts", "uncerts_ale", "psnrs", "ssims"}
+    assert z["img_inpainting"].shape == (3, 192, 192) and z["img_mask"].shape == (1, 192, 192) and 0.05 < 1 - z["img_mask"].mean() < 0.4
+    ps = z["psnrs"].item()["mfvi"]; ss = z["ssims"].item()["mfvi"]
+    assert ps.shape == (61, 3) and ss.shape == (61, 3) and np.isfinite(ps).all() and np.isfinite(ss).all()
+    assert ps[-1, 2] > ps[5, 2]                                      # the EMA reconstruction approaches the known pixels
+    assert z["recons"].item()["mfvi"].shape == (4, 3, 192, 192)
+    assert os.path.exists(os.path.join(r["run_dir"], "locals.txt")) and os.path.exists(os.path.join(r["run_dir"], "out_avg.png"))
+    # metric kernels vs numpy on the last recorded reconstruction
+    rec = z["recons"].item()["mfvi"][-1]; img = z["img_inpainting"]; mk = z["img_mask"]
+    psnr_np = 10 * np.log10(1.0 / np.mean((img * mk - rec * mk) ** 2))
+    assert abs(psnr_np - ps[-1, 2]) < 1e-3 * abs(psnr_np)
