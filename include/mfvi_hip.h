@@ -133,6 +133,13 @@ int mfvi_kl_backward(const float* mu, const float* rho, int64_t n, float prior_m
 /* ---- optimizer (torch.optim.AdamW(lr, weight_decay=0): bayesian_optimization.py:1356-1357,1372) --------- */
 int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int t, void* stream);
+/* AdamW with decoupled weight decay (the SGLD sibling: bayesian_optimization.py:1765-1766): p *= 1 - lr*weight_decay first */
+int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, int t, float weight_decay, void* stream);
+/* F.mse_loss(out[:, channel], target) of the non-Bayesian siblings (bayesian_optimization.py:1177, 1777): out[n][C][H][W],
+ * target[H][W]; mse_sum += sum_i mse_i; dout (optional, all C channels written) = grad_scale * d mse_i / d out_i. */
+int mfvi_mse_channel(const float* out, const float* target, int n, int C, int H, int W, int channel, float grad_scale,
+                     float* dout, double* mse_sum, void* stream);
 
 /* ---- RNG spec v1 on the device ----------------------------------------------------------------------------- */
 /* out[j] = a + b * N(0,1)  (e.g. z = z0 + 0.1*noise uses mfvi_axpy_normal) */
@@ -140,6 +147,11 @@ int mfvi_normal_fill(uint64_t seed, uint32_t domain, uint32_t stream_id, uint32_
                      float a, float b, float* out, void* stream);
 int mfvi_uniform_fill(uint64_t seed, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n, float scale,
                       float* out, void* stream);
+/* out[j] = lo + (hi - lo) * U[0,1)  (RNG domain 3): nn.Conv2d's default kaiming-uniform init of the DIP / SGLD siblings */
+int mfvi_uniform_fill_range(uint64_t seed, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n, float lo, float hi,
+                            float* out, void* stream);
+/* x[j] += std * N(0,1), RNG domain 4 (SGLD's add_noise on the conv weights: bayesian_optimization.py:166-170) */
+int mfvi_add_normal(float* x, uint64_t seed, uint32_t stream_id, uint32_t step, int64_t n, float std, void* stream);
 /* net_input = net_input_saved + std * N(0,1)  (bayesian_optimization.py:1363-1364), RNG domain 1 */
 int mfvi_perturb_input(const float* z0, uint64_t seed, uint32_t step, int64_t n, float std, float* z, void* stream);
 

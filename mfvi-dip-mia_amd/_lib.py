@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmfvi_hip.so")
 
 OP_CONV, OP_CONCAT_UP = 1, 2
-DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM = 0, 1, 2, 3
+DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD = 0, 1, 2, 3, 4
 
 
 class TensorDesc(C.Structure):
@@ -48,6 +48,10 @@ SIGNATURES = {
     "mfvi_kl": (_I, [_P, _P, _I64, _F, _F, _P, _P]),
     "mfvi_kl_backward": (_I, [_P, _P, _I64, _F, _F, _F, _P, _P, _P]),
     "mfvi_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _P]),
+    "mfvi_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
+    "mfvi_mse_channel": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "mfvi_uniform_fill_range": (_I, [_U64, _U32, _U32, _U32, _I64, _F, _F, _P, _P]),
+    "mfvi_add_normal": (_I, [_P, _U64, _U32, _U32, _I64, _F, _P]),
     "mfvi_normal_fill": (_I, [_U64, _U32, _U32, _U32, _U32, _I64, _F, _F, _P, _P]),
     "mfvi_uniform_fill": (_I, [_U64, _U32, _U32, _U32, _I64, _F, _P, _P]),
     "mfvi_perturb_input": (_I, [_P, _U64, _U32, _I64, _F, _P, _P]),

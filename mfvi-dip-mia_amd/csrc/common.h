@@ -85,7 +85,7 @@ __device__ __forceinline__ void spec_boxmuller(uint32_t a, uint32_t b, float& z0
     z1 = rad * sn;
 }
 
-enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3 };
+enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4 };
 
 struct RngKey {              // everything but the block index
     uint32_t k0, k1;         // seed lo/hi

@@ -75,6 +75,23 @@ __global__ __launch_bounds__(256) void gaussian_nll_inp_kernel(const float* __re
     block_atomic_add(acc * (double)inv_n, nll_sum, s_red);
 }
 
+// ---- mse_loss on one output channel (DIP / SGLD siblings) ----
+__global__ __launch_bounds__(256) void mse_channel_kernel(const float* __restrict__ out, const float* __restrict__ target, int C, long long HW,
+                                                          int channel, float grad_scale, float* __restrict__ dout, double* __restrict__ mse_sum)
+{
+    __shared__ double s_red[8];
+    const int k = blockIdx.y;
+    const float* __restrict__ o = out + (long long)k * C * HW;
+    float* __restrict__ d = dout ? dout + (long long)k * C * HW : nullptr;
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+        const float df = o[channel * HW + i] - target[i];
+        acc += (double)(df * df);
+        if (d) for (int c = 0; c < C; ++c) d[c * HW + i] = c == channel ? grad_scale * 2.f * df / (float)HW : 0.f;
+    }
+    block_atomic_add(acc / (double)HW, mse_sum, s_red);
+}
+
 // ---- KL ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ mu, const float* __restrict__ rho, long long n,
                                                  float m0, float s0, double* __restrict__ kl_out)
@@ -104,14 +121,14 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
 // ---- AdamW(wd = 0) ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float b1, float b2, float eps,
-                                                   float step_size, float inv_sqrt_bc2)
+                                                   float step_size, float inv_sqrt_bc2, float decay)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));       // decay = 1 - lr*wd (exactly 1 for wd = 0)
     }
 }
 
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) void normal_fill_kernel(RngKey key, long long 
         }
     }
 }
-__global__ __launch_bounds__(256) void uniform_fill_kernel(RngKey key, long long n, float scale, float* __restrict__ out)
+__global__ __launch_bounds__(256) void uniform_fill_kernel(RngKey key, long long n, float scale, float* __restrict__ out, float lo = 0.f)
 {
     const long long nblk = (n + 3) >> 2;
     for (long long blk = (long long)blockIdx.x * 256 + threadIdx.x; blk < nblk; blk += (long long)gridDim.x * 256) {
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(256) void uniform_fill_kernel(RngKey key, long long
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const long long j = blk * 4 + l;
-            if (j < n) out[j] = scale * ((float)(r[l] >> 8) * 5.9604644775390625e-08f);
+            if (j < n) out[j] = lo + scale * ((float)(r[l] >> 8) * 5.9604644775390625e-08f);
         }
     }
 }
@@ -454,7 +471,44 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f);
+    return (int)hipGetLastError();
+}
+
+int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
+                    float weight_decay, void* stream)
+{
+    if (n < 0 || t < 1 || weight_decay < 0.f) { set_error("adamw_step: bad arguments (t is 1-based)"); return -1; }
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f - lr * weight_decay);
+    return (int)hipGetLastError();
+}
+
+int mfvi_mse_channel(const float* out, const float* target, int n, int C, int H, int W, int channel, float grad_scale, float* dout,
+                     double* mse_sum, void* stream)
+{
+    if (!out || !target || !mse_sum || n < 1 || C < 1 || channel < 0 || channel >= C || H < 1 || W < 1) { set_error("mse_channel: bad arguments"); return -1; }
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(mse_channel_kernel, dim3(nblocks(HW, 16), n), dim3(256), 0, (hipStream_t)stream, out, target, C, HW, channel, grad_scale, dout, mse_sum);
+    return (int)hipGetLastError();
+}
+
+int mfvi_uniform_fill_range(uint64_t seed, uint32_t stream_id, uint32_t sample, uint32_t step, int64_t n, float lo, float hi, float* out,
+                            void* stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(uniform_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       make_key(seed, DOMAIN_UNIFORM, stream_id, sample, step), (long long)n, hi - lo, out, lo);
+    return (int)hipGetLastError();
+}
+
+int mfvi_add_normal(float* x, uint64_t seed, uint32_t stream_id, uint32_t step, int64_t n, float std, void* stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       make_key(seed, DOMAIN_SGLD, stream_id, 0, step), (long long)n, 0.f, std, (const float*)x, x);
     return (int)hipGetLastError();
 }
 
