@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MFVI_ABI_VERSION 1
+#define MFVI_ABI_VERSION 2
 
 typedef struct mfvi_plan mfvi_plan;
 
@@ -44,6 +44,9 @@ typedef struct {
     int32_t has_act;     /* LeakyReLU(slope) after the BN */
     float   slope;
     float   eps;
+    float   drop_p;      /* > 0: nn.Dropout2d(p) between the producing conv and the BN (models/common.py:125-131, the
+                          * MC-dropout sibling's nets); needs has_bn.  Channel c of sample k is kept iff u >= p with u the
+                          * U[0,1) of element c of stream <producing layer_id> in RNG domain 5, and scaled by 1/(1-p). */
     int64_t bn_off;      /* offset of gamma[C] (beta[C] follows) inside the BN block */
 } mfvi_tensor_desc;
 
@@ -67,6 +70,9 @@ int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_
                      int input_tensor, int output_tensor, int64_t n_vi, int64_t n_bn, int max_samples,
                      mfvi_plan** plan);
 void mfvi_plan_destroy(mfvi_plan* plan);
+/* Dropout2d layers of the program are active by default (the reference keeps its MC-dropout nets in train mode);
+ * enabled = 0 makes them the identity (nn.Dropout2d in eval mode). */
+int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled);
 /* bytes of caller-provided device workspace (activations, gradients, BN statistics) for max_samples */
 int64_t mfvi_plan_workspace_bytes(const mfvi_plan* plan);
 
@@ -136,9 +142,10 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 /* AdamW with decoupled weight decay (the SGLD sibling: bayesian_optimization.py:1765-1766): p *= 1 - lr*weight_decay first */
 int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, int t, float weight_decay, void* stream);
-/* F.mse_loss(out[:, channel], target) of the non-Bayesian siblings (bayesian_optimization.py:1177, 1777): out[n][C][H][W],
- * target[H][W]; mse_sum += sum_i mse_i; dout (optional, all C channels written) = grad_scale * d mse_i / d out_i. */
-int mfvi_mse_channel(const float* out, const float* target, int n, int C, int H, int W, int channel, float grad_scale,
+/* F.mse_loss(out[:, channel], target) of the non-Bayesian siblings (bayesian_optimization.py:1177, 1780; SR :1983-1985 with
+ * factor > 1 = the projection out[..., ::f, ::f] first): out[n][C][H][W], target[H/f][W/f]; mse_sum += sum_i mse_i;
+ * dout (optional, all C channels written) = grad_scale * d mse_i / d out_i. */
+int mfvi_mse_channel(const float* out, const float* target, int n, int C, int H, int W, int channel, int factor, float grad_scale,
                      float* dout, double* mse_sum, void* stream);
 
 /* ---- RNG spec v1 on the device ----------------------------------------------------------------------------- */

@@ -7,12 +7,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmfvi_hip.so")
 
 OP_CONV, OP_CONCAT_UP = 1, 2
-DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD = 0, 1, 2, 3, 4
+DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD, DOMAIN_DROPOUT = 0, 1, 2, 3, 4, 5
 
 
 class TensorDesc(C.Structure):
     _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("has_bn", C.c_int32), ("has_act", C.c_int32),
-                ("slope", C.c_float), ("eps", C.c_float), ("bn_off", C.c_int64)]
+                ("slope", C.c_float), ("eps", C.c_float), ("drop_p", C.c_float), ("bn_off", C.c_int64)]
 
 
 class OpDesc(C.Structure):
@@ -32,6 +32,7 @@ SIGNATURES = {
     "mfvi_plan_create": (_I, [_P, _I, _P, _I, _I, _I, _I64, _I64, _I, _P]),
     "mfvi_plan_destroy": (None, [_P]),
     "mfvi_plan_workspace_bytes": (_I64, [_P]),
+    "mfvi_plan_set_dropout": (_I, [_P, _I]),
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
     "mfvi_backward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mfvi_plan_read_tensor": (_I, [_P, _P, _I, _I, _I, _P, _P]),
@@ -49,7 +50,7 @@ SIGNATURES = {
     "mfvi_kl_backward": (_I, [_P, _P, _I64, _F, _F, _F, _P, _P, _P]),
     "mfvi_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _P]),
     "mfvi_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
-    "mfvi_mse_channel": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "mfvi_mse_channel": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_uniform_fill_range": (_I, [_U64, _U32, _U32, _U32, _I64, _F, _F, _P, _P]),
     "mfvi_add_normal": (_I, [_P, _U64, _U32, _U32, _I64, _F, _P]),
     "mfvi_normal_fill": (_I, [_U64, _U32, _U32, _U32, _U32, _I64, _F, _F, _P, _P]),

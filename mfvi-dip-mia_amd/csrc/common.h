@@ -85,7 +85,7 @@ __device__ __forceinline__ void spec_boxmuller(uint32_t a, uint32_t b, float& z0
     z1 = rad * sn;
 }
 
-enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4 };
+enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4, DOMAIN_DROPOUT = 5 };
 
 struct RngKey {              // everything but the block index
     uint32_t k0, k1;         // seed lo/hi
@@ -129,6 +129,7 @@ struct TView {
     const float* gamma;      // gamma[C], beta[C] follows at gamma + C
     float eps, slope;
     int act;
+    const float* drop;       // [n_samples][C] Dropout2d factors (0 or 1/(1-p)) applied between the raw data and the BN; nullptr: none
 };
 
 // Gradient wrt a raw tensor y, formed on load from ga = dL/d(BN output) (or dL/dy when no BN):
@@ -141,6 +142,7 @@ struct GView {
     const double* bsums;     // [n_samples][C][2] = sum ga, sum ga*xhat
     const float* gamma;
     float eps;
+    const float* drop;       // as TView::drop
 };
 
 // per-channel constants of a view, computed once per block into LDS/registers
@@ -155,7 +157,9 @@ __device__ __forceinline__ ChanFwd chan_fwd(const TView& v, int k, int c)
     const double* s = v.stats + ((long long)k * v.C + c) * 2;
     const double m = s[0] / n;
     double var = s[1] / n - m * m; if (var < 0) var = 0;
-    const double rstd = 1.0 / sqrt(var + (double)v.eps);
+    // Dropout2d factor d between y and the BN: BN(d*y) = (y - m) * (d*rstd_d) * gamma + beta with rstd_d = 1/sqrt(d^2 var + eps)
+    const double d = v.drop ? (double)v.drop[(long long)k * v.C + c] : 1.0;
+    const double rstd = d / sqrt(d * d * var + (double)v.eps);
     r.mean = (float)m; r.scale = (float)(rstd * (double)v.gamma[c]); r.beta = v.gamma[v.C + c]; r.rstd = (float)rstd;
     return r;
 }
@@ -174,7 +178,8 @@ __device__ __forceinline__ ChanBwd chan_bwd(const GView& g, int k, int c)
     const double* b = g.bsums + ((long long)k * g.C + c) * 2;
     const double m = s[0] / n;
     double var = s[1] / n - m * m; if (var < 0) var = 0;
-    const double rstd = 1.0 / sqrt(var + (double)g.eps);
+    const double d = g.drop ? (double)g.drop[(long long)k * g.C + c] : 1.0;
+    const double rstd = d / sqrt(d * d * var + (double)g.eps);          // xhat = (y - m) * rstd, dy = d * gamma * rstd_d * (...)
     r.mean = (float)m; r.rstd = (float)rstd; r.c1 = (float)(rstd * (double)g.gamma[c]);
     r.c2 = (float)(b[0] / n); r.c3 = (float)(b[1] / n);
     return r;
@@ -294,6 +299,9 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
 int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int nearest, int n_samples, hipStream_t st);
 int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long ga_a_sstride, double* bsums_a,
                          const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int nearest, int n_samples, hipStream_t st);
+// Dropout2d factors of one forward: arena[e.drop_off + k*C + c] for every entry, sample k, channel c (RNG domain 5, stream layer_id)
+struct DropEntry { long long drop_off; int C, layer_id; float p; int pad; };
+int launch_dropout_masks(const DropEntry* table_dev, int n_entries, RngKey key, int n_samples, float* arena, hipStream_t st);
 struct BnGradEntry { long long bsums_off; long long bn_off; int C; int pad; };
 int launch_bn_param_grads(const BnGradEntry* table_dev, int n_entries, int max_c, const double* bsums_base, int n_samples,
                           float* dbn, hipStream_t st);

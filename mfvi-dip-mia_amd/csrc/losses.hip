@@ -75,21 +75,46 @@ __global__ __launch_bounds__(256) void gaussian_nll_inp_kernel(const float* __re
     block_atomic_add(acc * (double)inv_n, nll_sum, s_red);
 }
 
-// ---- mse_loss on one output channel (DIP / SGLD siblings) ----
-__global__ __launch_bounds__(256) void mse_channel_kernel(const float* __restrict__ out, const float* __restrict__ target, int C, long long HW,
-                                                          int channel, float grad_scale, float* __restrict__ dout, double* __restrict__ mse_sum)
+// ---- mse_loss on one output channel (DIP / SGLD siblings), optionally after the SR projection out[..., ::f, ::f] ----
+__global__ __launch_bounds__(256) void mse_channel_kernel(const float* __restrict__ out, const float* __restrict__ target, int C, int H, int W,
+                                                          int channel, int f, float grad_scale, float* __restrict__ dout, double* __restrict__ mse_sum)
 {
     __shared__ double s_red[8];
     const int k = blockIdx.y;
+    const long long HW = (long long)H * W;
+    const int w = W / f; const long long n = (long long)(H / f) * w;
     const float* __restrict__ o = out + (long long)k * C * HW;
     float* __restrict__ d = dout ? dout + (long long)k * C * HW : nullptr;
+    const float gs = grad_scale * 2.f / (float)n;
     double acc = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
-        const float df = o[channel * HW + i] - target[i];
-        acc += (double)(df * df);
-        if (d) for (int c = 0; c < C; ++c) d[c * HW + i] = c == channel ? grad_scale * 2.f * df / (float)HW : 0.f;
+        const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        float g = 0.f;
+        if (y % f == 0 && x % f == 0 && y / f < H / f && x / f < w) {
+            const float df = o[channel * HW + i] - target[(long long)(y / f) * w + x / f];
+            acc += (double)(df * df); g = gs * df;
+        }
+        if (d) for (int c = 0; c < C; ++c) d[c * HW + i] = c == channel ? g : 0.f;
     }
-    block_atomic_add(acc / (double)HW, mse_sum, s_red);
+    block_atomic_add(acc / (double)n, mse_sum, s_red);
+}
+
+// ---- Dropout2d masks (MC-dropout sibling) ----
+__global__ __launch_bounds__(64) void dropout_mask_kernel(const DropEntry* __restrict__ table, RngKey key, float* __restrict__ arena)
+{
+    const DropEntry e = table[blockIdx.x];
+    const int k = blockIdx.y;
+    key.stream = ((uint32_t)DOMAIN_DROPOUT << 24) | (uint32_t)e.layer_id;
+    key.sample += (uint32_t)k;
+    const float keep = 1.0f / (1.0f - e.p);
+    float* __restrict__ d = arena + e.drop_off + (long long)k * e.C;
+    for (int blk = threadIdx.x; blk * 4 < e.C; blk += 64) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)blk, key.stream, key.sample, key.step, key.k0, key.k1, r);
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (blk * 4 + l < e.C) d[blk * 4 + l] = (float)(r[l] >> 8) * 5.9604644775390625e-08f >= e.p ? keep : 0.0f;
+    }
 }
 
 // ---- KL ---------------------------------------------------------------------------------------
@@ -403,6 +428,13 @@ __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* 
 
 }  // namespace
 
+int launch_dropout_masks(const DropEntry* table_dev, int n_entries, RngKey key, int n_samples, float* arena, hipStream_t st)
+{
+    if (n_entries <= 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(n_entries, n_samples), dim3(64), 0, st, table_dev, key, arena);
+    return (int)hipGetLastError();
+}
+
 int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const float* mu, const float* rho, RngKey key,
                           int n_samples, float* wsamp, long long wstride, hipStream_t st)
 {
@@ -486,12 +518,13 @@ int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
     return (int)hipGetLastError();
 }
 
-int mfvi_mse_channel(const float* out, const float* target, int n, int C, int H, int W, int channel, float grad_scale, float* dout,
+int mfvi_mse_channel(const float* out, const float* target, int n, int C, int H, int W, int channel, int factor, float grad_scale, float* dout,
                      double* mse_sum, void* stream)
 {
-    if (!out || !target || !mse_sum || n < 1 || C < 1 || channel < 0 || channel >= C || H < 1 || W < 1) { set_error("mse_channel: bad arguments"); return -1; }
-    const long long HW = (long long)H * W;
-    hipLaunchKernelGGL(mse_channel_kernel, dim3(nblocks(HW, 16), n), dim3(256), 0, (hipStream_t)stream, out, target, C, HW, channel, grad_scale, dout, mse_sum);
+    if (!out || !target || !mse_sum || n < 1 || C < 1 || channel < 0 || channel >= C || H < 1 || W < 1 || factor < 1 || H / factor < 1 || W / factor < 1) {
+        set_error("mse_channel: bad arguments"); return -1; }
+    hipLaunchKernelGGL(mse_channel_kernel, dim3(nblocks((long long)H * W, 16), n), dim3(256), 0, (hipStream_t)stream, out, target, C, H, W, channel, factor,
+                       grad_scale, dout, mse_sum);
     return (int)hipGetLastError();
 }
 

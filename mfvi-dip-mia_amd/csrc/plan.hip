@@ -25,6 +25,7 @@ struct TensorInfo {
     long long numel = 0;
     long long act_off = -1, ga_off = -1;       // floats, from the float arena base
     long long stats_off = -1;                  // doubles, inside the fwd-stats block (same offset in the bsums block)
+    long long drop_off = -1;                   // floats: Dropout2d factors [max_samples][C] (drop_p > 0 only)
     int producer = -1;
     std::vector<int> consumers;                // op indices, forward order
 };
@@ -55,6 +56,7 @@ struct mfvi_plan {
     // identity of the draw currently held in the sampled-weight slab (set by forward, reused by the matching backward)
     const void* samp_mu = nullptr; const void* samp_rho = nullptr; const void* samp_ws = nullptr;
     uint64_t samp_seed = 0; uint32_t samp_step = 0, samp_k0 = 0; int samp_n = 0;
+    DropEntry* drop_dev = nullptr; int n_drop = 0; bool dropout_on = true;   // Dropout2d layers (MC-dropout sibling)
     GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
     std::vector<GradFinEntry> fin_uploaded;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
@@ -84,6 +86,8 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         if (ti.d.C < 1 || ti.d.H < 1 || ti.d.W < 1 || ti.d.C > MFVI_MAX_C) return fail("plan: tensor %d has bad shape (%d,%d,%d)", i, ti.d.C, ti.d.H, ti.d.W);
         if (ti.d.has_act && !ti.d.has_bn) return fail("plan: tensor %d: activation without BatchNorm is not part of the skip() family", i);
         if (ti.d.has_bn && (ti.d.bn_off < 0 || ti.d.bn_off + 2LL * ti.d.C > p.n_bn)) return fail("plan: tensor %d: bn_off out of range", i);
+        if (!(ti.d.drop_p >= 0.f && ti.d.drop_p < 1.f)) return fail("plan: tensor %d: dropout probability %g outside [0, 1)", i, (double)ti.d.drop_p);
+        if (ti.d.drop_p > 0.f && !ti.d.has_bn) return fail("plan: tensor %d: Dropout2d without a following BatchNorm is not part of the skip() family", i);
         ti.numel = (long long)ti.d.C * ti.d.H * ti.d.W;
     }
     if (p.t[p.input].d.has_bn) return fail("plan: the input tensor cannot carry a BatchNorm");
@@ -132,6 +136,8 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
                 return fail("plan: op %d reads tensor %d before it is produced", i, ins[q]);
     }
     for (int i = 0; i < n_t; ++i) {
+        if (p.t[i].d.drop_p > 0.f && (p.t[i].producer < 0 || p.ops[p.t[i].producer].d.type != MFVI_OP_CONV))
+            return fail("plan: tensor %d: Dropout2d must follow a convolution", i);
         if (i != p.input && p.t[i].producer < 0) return fail("plan: tensor %d is never produced", i);
         if (i != p.output && p.t[i].consumers.empty()) return fail("plan: tensor %d is never consumed", i);
         if (i == p.output && !p.t[i].consumers.empty()) return fail("plan: the output tensor has consumers");
@@ -156,6 +162,19 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     for (int i = 0; i < n_t; ++i) {
         if (i != p.input && i != p.output) p.t[i].act_off = take(p.t[i].numel * p.max_samples);
         if (i != p.output && i != p.input) p.t[i].ga_off = take(p.t[i].numel * p.max_samples);
+    }
+    std::vector<DropEntry> drops;
+    for (int i = 0; i < n_t; ++i)
+        if (p.t[i].d.drop_p > 0.f) {
+            p.t[i].drop_off = take((long long)p.t[i].d.C * p.max_samples);
+            DropEntry e{}; e.drop_off = p.t[i].drop_off; e.C = p.t[i].d.C; e.layer_id = p.ops[p.t[i].producer].d.layer_id; e.p = p.t[i].d.drop_p;
+            drops.push_back(e);
+        }
+    p.n_drop = (int)drops.size();
+    if (p.n_drop) {
+        hipError_t e = hipMalloc((void**)&p.drop_dev, sizeof(DropEntry) * drops.size());
+        if (e == hipSuccess) e = hipMemcpy(p.drop_dev, drops.data(), sizeof(DropEntry) * drops.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail("plan: dropout table setup failed: %s", hipGetErrorString(e));
     }
     long long shared_scratch = 0;
     for (auto& o : p.ops)
@@ -241,6 +260,7 @@ struct Ctx {
         v.stats = t.d.has_bn ? fstats() + t.stats_off : nullptr;
         v.gamma = t.d.has_bn ? bn + t.d.bn_off : nullptr;
         v.eps = t.d.eps; v.slope = t.d.slope; v.act = t.d.has_act;
+        v.drop = (t.drop_off >= 0 && p.dropout_on) ? farena() + t.drop_off : nullptr;
         return v;
     }
     GView gview(int i, const float* dout) const
@@ -253,6 +273,7 @@ struct Ctx {
         g.bsums = t.d.has_bn ? bsums() + t.stats_off : nullptr;
         g.gamma = t.d.has_bn ? bn + t.d.bn_off : nullptr;
         g.eps = t.d.eps;
+        g.drop = (t.drop_off >= 0 && p.dropout_on) ? farena() + t.drop_off : nullptr;
         return g;
     }
 };
@@ -287,7 +308,7 @@ int mfvi_plan_create(const mfvi_tensor_desc* tensors, int n_tensors, const mfvi_
     if (!tensors || !ops || !plan) { set_error("plan_create: null argument"); return -1; }
     mfvi_plan* p = new mfvi_plan();
     p->input = input_tensor; p->output = output_tensor; p->n_vi = n_vi; p->n_bn = n_bn; p->max_samples = max_samples;
-    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); if (p->fin_dev) (void)hipFree(p->fin_dev); if (p->samp_dev) (void)hipFree(p->samp_dev); delete p; *plan = nullptr; return -1; }
+    if (!build(*p, tensors, n_tensors, ops, n_ops)) { if (p->table_dev) (void)hipFree(p->table_dev); if (p->drop_dev) (void)hipFree(p->drop_dev); if (p->fin_dev) (void)hipFree(p->fin_dev); if (p->samp_dev) (void)hipFree(p->samp_dev); delete p; *plan = nullptr; return -1; }
     *plan = p;
     return 0;
 }
@@ -300,10 +321,18 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     if (plan->table_dev) (void)hipFree(plan->table_dev);
     if (plan->fin_dev) (void)hipFree(plan->fin_dev);
     if (plan->samp_dev) (void)hipFree(plan->samp_dev);
+    if (plan->drop_dev) (void)hipFree(plan->drop_dev);
     delete plan;
 }
 
 int64_t mfvi_plan_workspace_bytes(const mfvi_plan* plan) { return plan ? plan->total_bytes : -1; }
+
+int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled)
+{
+    if (!plan) { set_error("set_dropout: null plan"); return -1; }
+    plan->dropout_on = enabled != 0;
+    return 0;
+}
 
 int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, uint64_t seed, uint32_t step,
                  uint32_t k0, int n_samples, int sample_weights, void* workspace, float* out, void* stream)
@@ -324,6 +353,10 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
         if (rc) { set_error("forward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
         plan->samp_mu = mu; plan->samp_rho = rho; plan->samp_ws = workspace; plan->samp_seed = seed; plan->samp_step = step; plan->samp_k0 = k0; plan->samp_n = n_samples;
+    }
+    if (plan->n_drop && plan->dropout_on) {      // Dropout2d factors of this pass; the backward reads them from the workspace
+        const int rc = launch_dropout_masks(plan->drop_dev, plan->n_drop, key, n_samples, c.farena(), st);
+        if (rc) { set_error("forward: dropout mask launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
     for (size_t i = 0; i < plan->ops.size(); ++i) {

@@ -67,6 +67,7 @@ class ElboEngine:
             self.ct_scratch = torch.empty(self.chunk * len(th) * W, dtype=torch.float32, device=dev)
         self.t = 0
         self.target = None
+        self.sample_weights = True       # w = mu + softplus(rho) * eps; the non-Bayesian siblings run w = mu
         self.init_params()
         if autotune:      # one-time: pick the fastest kernel tiling per layer on this device (results unchanged)
             self.plan.autotune(self.mu, self.rho, self.bn, self.z0, self.chunk)
@@ -104,7 +105,8 @@ class ElboEngine:
             L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
         for c0 in range(0, self.K_local, self.chunk):
             n = min(self.chunk, self.K_local - c0)
-            self.plan.forward(self.mu, self.rho, self.bn, self.z if perturb else self.z0, self.seed, step, self.k0 + c0, n, True, self.out)
+            self.plan.forward(self.mu, self.rho, self.bn, self.z if perturb else self.z0, self.seed, step, self.k0 + c0, n, self.sample_weights,
+                              self.out)
         return self.out
 
     def _loss_and_dout(self, n):
@@ -132,9 +134,10 @@ class ElboEngine:
             zsrc = self.z
         for c0 in range(0, self.K_local, self.chunk):
             n = min(self.chunk, self.K_local - c0)
-            self.plan.forward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, True, self.out)
+            self.plan.forward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.sample_weights, self.out)
             self._loss_and_dout(n)
-            self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn, True)
+            self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn,
+                               self.sample_weights)
         if self.world > 1:
             # the single exchange of the K-sharded step: grads (+ the NLL scalar) summed over ranks
             self.grads[self.n_params] = self.acc[0].float()
@@ -161,3 +164,82 @@ class ElboEngine:
             nll = float(self.acc[0]) / self.K
         kl = float(self.acc[1])
         return nll, kl, nll + self.temp * kl
+
+
+METHOD_DIP, METHOD_MCD, METHOD_SGLD = "dip", "mcd", "sgld"
+
+
+class SiblingEngine(ElboEngine):
+    """The reference's non-Bayesian comparison methods on the same layer program and kernels:
+
+    dip   plain deep image prior: w = mu, MSE on the image channel, AdamW(wd=0)      (bayesian_optimization.py:1064-1237)
+    mcd   MC dropout: Dropout2d(p) after the deeper / up convolutions (train mode throughout), heteroscedastic NLL,
+          AdamW(weight_decay)                                                          (bayesian_optimization.py:1447-1655)
+    sgld  N(0, (2*lr0)^2) noise on the 4-D conv weights before every forward (add_noise, :166-170), MSE (den) / NLL (sr),
+          AdamW(weight_decay) with ExponentialLR(gamma) while lr > 1e-8               (bayesian_optimization.py:1658-1860)
+
+    Parameters live in the MU block (RHO is unused, zero); nn.Conv2d's default initialisation (kaiming-uniform with a = sqrt(5):
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias) is drawn from the RNG spec."""
+
+    def __init__(self, H, W, method=METHOD_DIP, task=TASK_DEN, weight_decay=0.0, dropout_p=0.3, gamma=0.996, param_noise_sigma=2.0,
+                 net_kwargs=None, **kw):
+        if method not in (METHOD_DIP, METHOD_MCD, METHOD_SGLD):
+            raise ValueError("method %r: 'dip', 'mcd' or 'sgld'" % (method,))
+        if task == TASK_INP and method == METHOD_DIP:
+            raise NotImplementedError("run_inp_dip's masked MSE on the sigmoid output is not built")
+        self.method = method
+        self.weight_decay, self.gamma, self.param_noise_sigma = float(weight_decay), float(gamma), float(param_noise_sigma)
+        nk = dict(net_kwargs or {})
+        if method == METHOD_MCD:
+            nk.update(drop_down=float(dropout_p), drop_up=float(dropout_p))
+        kw.pop("temp", None); kw.pop("sigma", None)
+        super().__init__(H, W, task=task, temp=0.0, sigma=0.0, net_kwargs=nk, **kw)
+        self.lr0 = self.lr                    # add_noise keeps using the initial rate (LR, not the scheduler's)
+
+    def init_params(self):
+        lib, sp = L.lib(), L.stream_ptr()
+        self.sample_weights = False
+        self.params.zero_()
+        for lid, lay in enumerate(self.prog.layers):
+            bound = 1.0 / math.sqrt(lay["cin"] * lay["k"] * lay["k"])
+            n = lay["cout"] * lay["cin"] * lay["k"] * lay["k"] + (lay["cout"] if lay["b_off"] >= 0 else 0)
+            L.check(lib.mfvi_uniform_fill_range(self.seed, 16 + lid, 0, 0, n, -bound, bound, L.ptr(self.mu[lay["w_off"]:]), sp))
+        for b in self.prog.bns:
+            self.bn[b["off"]:b["off"] + b["C"]] = 1.0
+        L.check(lib.mfvi_uniform_fill(self.seed, 0, 0, 0, self.z0.numel(), 0.1, L.ptr(self.z0), sp))
+        self.m.zero_(); self.v.zero_(); self.t = 0
+
+    def _loss_and_dout(self, n):
+        lib, sp = L.lib(), L.stream_ptr()
+        mse_image = self.method == METHOD_DIP or (self.method == METHOD_SGLD and self.task == TASK_DEN)
+        if self.task in (TASK_DEN, TASK_SR) and mse_image:      # F.mse_loss(out[:, :1], target)  (:1177, :1780, :1985)
+            f = self.sr_factor if self.task == TASK_SR else 1
+            L.check(lib.mfvi_mse_channel(L.ptr(self.out), L.ptr(self.target), n, self.out.shape[1], self.H, self.W, 0, f, 1.0 / self.K,
+                                         L.ptr(self.dout), L.ptr(self.acc), sp))
+        else:                                                    # gaussian_nll / radon MSE / masked NLL as in the MFVI runners
+            super()._loss_and_dout(n)
+
+    def add_noise(self, step):
+        """add_noise(net, param_noise_sigma, LR): 4-D parameters (the conv weights) only, std = sigma * lr0 (RNG domain 4)."""
+        lib, sp = L.lib(), L.stream_ptr()
+        std = self.param_noise_sigma * self.lr0
+        for lid, lay in enumerate(self.prog.layers):
+            n = lay["cout"] * lay["cin"] * lay["k"] * lay["k"]
+            L.check(lib.mfvi_add_normal(L.ptr(self.mu[lay["w_off"]:]), self.seed, lid, step, n, std, sp))
+
+    def step(self):
+        lib, sp = L.lib(), L.stream_ptr()
+        if self.method == METHOD_SGLD:
+            self.add_noise(self.t)
+        self.grad_only(self.t, with_kl=False)
+        self.t += 1
+        n = self.n_vi
+        for lo, hi in ((0, n), (2 * n, self.n_params)):          # MU block and BN block; RHO does not exist for these methods
+            L.check(lib.mfvi_adamw_step(L.ptr(self.params[lo:]), L.ptr(self.grads[lo:]), L.ptr(self.m[lo:]), L.ptr(self.v[lo:]), hi - lo,
+                                        self.lr, 0.9, 0.999, 1e-8, self.t, self.weight_decay, sp))
+        if self.method == METHOD_SGLD and self.lr > 1e-8:        # scheduler.step() while get_last_lr() > 1e-8 (:1784-1785)
+            self.lr *= self.gamma
+
+    def losses(self):
+        loss, _, _ = super().losses()
+        return loss, 0.0, loss

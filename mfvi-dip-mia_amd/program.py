@@ -23,7 +23,7 @@ class Program:
             off = self.n_bn
             self.n_bn += 2 * C_
             self.bns.append(dict(C=C_, off=off, tensor=len(self.tensors)))
-        self.tensors.append(dict(C=C_, H=H, W=W, has_bn=int(bn), has_act=int(act), slope=slope, eps=eps, bn_off=off))
+        self.tensors.append(dict(C=C_, H=H, W=W, has_bn=int(bn), has_act=int(act), slope=slope, eps=eps, drop_p=0.0, bn_off=off))
         return len(self.tensors) - 1
 
     def set_bn(self, tid, act, slope=0.2, eps=1e-5):
@@ -34,6 +34,12 @@ class Program:
         t.update(has_bn=1, has_act=int(act), slope=slope, eps=eps, bn_off=self.n_bn)
         self.bns.append(dict(C=t["C"], off=self.n_bn, tensor=tid))
         self.n_bn += 2 * t["C"]
+
+    def set_dropout(self, tid, p):
+        """nn.Dropout2d(p) directly after the conv that produces tensor `tid` (before its BatchNorm)."""
+        if not 0.0 <= p < 1.0:
+            raise ValueError("dropout probability %r outside [0, 1)" % (p,))
+        self.tensors[tid]["drop_p"] = float(p)
 
     def conv(self, in_id, out_id, ksize, stride=1, bias=True):
         cin, cout = self.tensors[in_id]["C"], self.tensors[out_id]["C"]
@@ -167,12 +173,14 @@ class Plan:
 
 
 def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(16, 32, 64, 128, 128), ns=(4, 4, 4, 4, 4),
-                 fd=3, fu=3, fs=1, need1x1_up=True, upsample_mode="bilinear"):
+                 fd=3, fu=3, fs=1, need1x1_up=True, upsample_mode="bilinear", drop_down=0.0, drop_up=0.0):
     """The skip() hour-glass of the reference (models/skip.py:58-134) as a layer program, in module order:
     per scale  [skip-conv/BN/act], down-conv(s2)/BN/act, conv/BN/act, [deeper scale], Upsample, [Concat], BN,
     up-conv/BN/act, [1x1-conv/BN/act]; then the final 1x1 conv.  ns[i] == 0 drops the skip branch and its Concat
     (models/skip.py:62-66), need1x1_up / filter sizes / upsample_mode as in the inpainting runner
-    (bayesian_optimization.py:2970-2998).  Returns (program, input_id, output_id, tensor-id map)."""
+    (bayesian_optimization.py:2970-2998).  drop_down / drop_up > 0 put nn.Dropout2d(p) after the deeper / up convolutions
+    (dropout_mode_down = dropout_mode_up = '2d' of the MC-dropout runners, bayesian_optimization.py:1526-1549).
+    Returns (program, input_id, output_id, tensor-id map)."""
     P = Program()
     names = {}
     zin = P.tensor(input_depth, H, W)
@@ -192,6 +200,9 @@ def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(1
         top_i = u
         if need1x1_up:
             top_i = P.tensor(nu[i], h, w); P.conv(u, top_i, 1, 1); P.set_bn(top_i, act=True)
+        for t, p in ((d1, drop_down), (d2, drop_down), (u, drop_up)) + (((top_i, drop_up),) if need1x1_up else ()):
+            if p:
+                P.set_dropout(t, p)
         names[i] = dict(skip=s, d1=d1, d2=d2, cat=cat, up=u, up1=top_i)
         return top_i
 

@@ -438,8 +438,98 @@ def golden_inpainting():
     print("inpainting ok: nll", float(nll), "layers", len(layers))
 
 
+def golden_siblings():
+    """The non-Bayesian siblings on the reference's own skip() net with plain nn.Conv2d:
+    DIP (bayesian_optimization.py:1064-1237), MC dropout (:1447-1655, the reference's conv() builds the nn.Dropout2d layers;
+    masks injected from RNG domain 5) and SGLD (:1658-1860; add_noise :166-170 restated with noise injected from RNG domain 4),
+    torch AdamW(weight_decay) and ExponentialLR.  Three optimizer steps each; first-step output / gradients and the
+    final parameters are stored."""
+    import torch.nn.functional as F
+    onet_args = dict(input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+    H = W = 32; steps = 3; seed = 41; lr = 3e-4
+    res = dict(H=H, W=W, steps=steps, seed=seed, lr=lr)
+    for method, p_drop, wd, gamma in (("dip", 0.0, 0.0, 1.0), ("mcd", 0.3, 3e-4, 1.0), ("sgld", 0.0, 5e-8, 0.996)):
+        onet = O.make_net(H, W, drop_down=p_drop, drop_up=p_drop, **onet_args)
+        conv, bn, n_vi, n_bnp = O.net_table(onet)
+        mu, _, bnp = test_params(onet, seed)
+        mode = '2d' if p_drop else 'None'
+        n = onet.n_scales
+        net = R["mskip"].skip(onet.input_depth, onet.n_out, num_channels_down=[onet.nd[i] for i in range(n)],
+                              num_channels_up=[onet.nu[i] for i in range(n)], num_channels_skip=[onet.ns[i] for i in range(n)],
+                              upsample_mode='bilinear', downsample_mode='stride', need_sigmoid=False, need_bias=True, pad='reflection',
+                              act_fun='LeakyReLU', dropout_mode_down=mode, dropout_p_down=p_drop, dropout_mode_up=mode, dropout_p_up=p_drop,
+                              dropout_mode_skip='None', dropout_mode_output='None')
+        convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+        assert len(convs) == len(conv)
+        with torch.no_grad():
+            for m, row in zip(convs, conv):
+                cin, cout, k, stride, w_off, b_off = [int(v) for v in row]
+                m.weight.copy_(torch.from_numpy(mu[w_off:w_off + cout * cin * k * k].reshape(cout, cin, k, k)))
+                m.bias.copy_(torch.from_numpy(mu[b_off:b_off + cout]))
+            for m, (c, off) in zip(bn_layers(net), bn):
+                c, off = int(c), int(off)
+                m.weight.copy_(torch.from_numpy(bnp[off:off + c])); m.bias.copy_(torch.from_numpy(bnp[off + c:off + 2 * c]))
+        state = dict(layer=-1, step=0)
+        for lid, m in enumerate(convs):
+            m.register_forward_pre_hook(lambda mod, inp, lid=lid: state.__setitem__("layer", lid))
+
+        def dropout2d(x, p=0.5, training=True, inplace=False):
+            assert training and x.shape[0] == 1
+            d = O.dropout_mask(seed, state["step"], 0, state["layer"], p, x.shape[1])
+            return x * torch.from_numpy(d)[None, :, None, None]
+        orig = F.dropout2d; F.dropout2d = dropout2d
+        try:
+            z0 = (0.1 * O.uniform_fill(seed, 0, 0, 0, onet.input_depth * H * W)).reshape(1, onet.input_depth, H, W)
+            tgt = torch.from_numpy(O.noisy(O.phantom(H, W, seed), 0.1, seed))[None, None]
+            opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=wd)
+            sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=gamma) if method == "sgld" else None
+            losses = []
+            for it in range(steps):
+                state["step"] = it
+                opt.zero_grad()
+                if method == "sgld":          # add_noise(net, 2, LR): 4-D parameters only, noise * sigma * lr0
+                    for lid, m in enumerate(convs):
+                        nz = O.normal_fill(seed, 4, lid, 0, it, m.weight.numel()).reshape(tuple(m.weight.shape))
+                        m.weight.data = m.weight.data + torch.from_numpy(nz) * 2 * lr
+                zn = O.normal_fill(seed, 1, 0, 0, it, z0.size).reshape(z0.shape)
+                out = net(torch.from_numpy(z0 + 0.1 * zn))
+                if method == "mcd":
+                    loss = R["bu"].gaussian_nll(out[:, :1], out[:, 1:], tgt)
+                else:
+                    loss = F.mse_loss(out[:, :1], tgt)
+                loss.backward()
+                if it == 0:
+                    g_mu = np.zeros(n_vi, np.float32); g_bn = np.zeros(n_bnp, np.float32)
+                    for m, row in zip(convs, conv):
+                        cin, cout, k, stride, w_off, b_off = [int(v) for v in row]
+                        g_mu[w_off:w_off + cout * cin * k * k] = m.weight.grad.numpy().ravel(); g_mu[b_off:b_off + cout] = m.bias.grad.numpy()
+                    for m, (c, off) in zip(bn_layers(net), bn):
+                        c, off = int(c), int(off)
+                        g_bn[off:off + c] = m.weight.grad.numpy(); g_bn[off + c:off + 2 * c] = m.bias.grad.numpy()
+                    res[method + "_out0"] = out.detach().numpy()[0].copy(); res[method + "_dmu0"] = g_mu; res[method + "_dbn0"] = g_bn
+                opt.step()
+                if sched is not None and sched.get_last_lr()[0] > 1e-8:
+                    sched.step()
+                losses.append(float(loss))
+        finally:
+            F.dropout2d = orig
+        f_mu = np.zeros(n_vi, np.float32); f_bn = np.zeros(n_bnp, np.float32)
+        for m, row in zip(convs, conv):
+            cin, cout, k, stride, w_off, b_off = [int(v) for v in row]
+            f_mu[w_off:w_off + cout * cin * k * k] = m.weight.detach().numpy().ravel(); f_mu[b_off:b_off + cout] = m.bias.detach().numpy()
+        for m, (c, off) in zip(bn_layers(net), bn):
+            c, off = int(c), int(off)
+            f_bn[off:off + c] = m.weight.detach().numpy(); f_bn[off + c:off + 2 * c] = m.bias.detach().numpy()
+        res.update({method + "_loss": np.array(losses), method + "_mu": f_mu, method + "_bn": f_bn, method + "_wd": wd,
+                    method + "_gamma": gamma, method + "_p": p_drop})
+        print("sibling", method, "losses", losses)
+    np.savez_compressed(os.path.join(GOLD, "siblings.npz"), **res)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--siblings" in sys.argv:
+        golden_siblings(); sys.exit(0)
     if "--inpainting" in sys.argv:       # only the inpainting fixtures (the others are unchanged)
         golden_inpainting(); sys.exit(0)
     golden_layers()
@@ -453,3 +543,4 @@ if __name__ == "__main__":
     golden_traj("traj_small_k1", small, seed=31, K=1, steps=4)
     golden_traj("traj_small_k2", small, seed=32, K=2, steps=3)
     golden_inpainting()
+    golden_siblings()

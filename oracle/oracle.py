@@ -27,12 +27,14 @@ def build(force=False):
 class OracleNet(C.Structure):
     _fields_ = [("n_scales", C.c_int), ("nd", C.c_int * MAXS), ("nu", C.c_int * MAXS), ("ns", C.c_int * MAXS),
                 ("input_depth", C.c_int), ("n_out", C.c_int), ("fd", C.c_int), ("fu", C.c_int), ("fs", C.c_int),
-                ("H", C.c_int), ("W", C.c_int)]
+                ("H", C.c_int), ("W", C.c_int), ("drop_down", C.c_float), ("drop_up", C.c_float)]
 
 
 def make_net(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(16, 32, 64, 128, 128), ns=(4, 4, 4, 4, 4),
-             fd=3, fu=3, fs=1):
+             fd=3, fu=3, fs=1, drop_down=0.0, drop_up=0.0):
+    """drop_down / drop_up: Dropout2d(p) after the deeper / up convolutions (the MC-dropout sibling's net)."""
     n = OracleNet()
+    n.drop_down, n.drop_up = drop_down, drop_up
     n.n_scales = len(nd)
     for i in range(len(nd)):
         n.nd[i], n.nu[i], n.ns[i] = nd[i], nu[i], ns[i]
@@ -200,6 +202,18 @@ def adam(p, g, m, v, lr, t):
     lib().oracle_adam(_p(p), _p(g), _p(m), _p(v), C.c_long(p.size), C.c_float(lr), C.c_int(t))
 
 
+def adamw(p, g, m, v, lr, t, wd):
+    """torch.optim.AdamW with decoupled weight decay, in place."""
+    lib().oracle_adamw(_p(p), _p(g), _p(m), _p(v), C.c_long(p.size), C.c_float(lr), C.c_int(t), C.c_float(wd))
+
+
+def dropout_mask(seed, step, sample, layer, p, n_channels):
+    """Dropout2d factors (0 or 1/(1-p)) of conv layer `layer` for one forward (RNG domain 5)."""
+    d = np.zeros(n_channels, np.float32)
+    lib().oracle_dropout_mask(C.c_uint64(seed), C.c_uint32(step), C.c_uint32(sample), C.c_int(layer), C.c_float(p), C.c_int(n_channels), _p(d))
+    return d
+
+
 def psnr(a, b):
     a, b = _f(a), _f(b); return lib().oracle_psnr(_p(a), _p(b), C.c_long(a.size))
 
@@ -290,6 +304,35 @@ def elbo_grad(net, mu, rho, bn, z, target, task=0, factor=4, theta_deg=None, see
                                   C.c_int(1 if with_kl else 0), _p(dmu), _p(drho), _p(dbn), _p(outs),
                                   C.byref(nll), C.byref(klv))
     return dict(loss=loss, nll=nll.value, kl=klv.value, dmu=dmu, drho=drho, dbn=dbn, out=outs)
+
+
+def sibling_grad(net, mu, bn, z, target, loss="mse0", seed=1, step=0, k0=0, K=1, K_total=None, want_out=False):
+    """Gradient of the non-Bayesian siblings' loss (DIP / SGLD: F.mse_loss(out[:, :1], y), bayesian_optimization.py:1177,1780;
+    MC dropout: gaussian_nll, :1578) averaged over K forwards of the deterministic-weight net (w = mu); Dropout2d masks, when
+    the net has them, come from RNG domain 5 keyed by (step, sample)."""
+    mu, bn, z, target = _f(mu), _f(bn), _f(z), _f(target)
+    K_total = K if K_total is None else K_total
+    _, _, n_vi, n_bnp = net_table(net)
+    rho = np.zeros_like(mu)
+    dmu = np.zeros(n_vi, np.float64); dbn = np.zeros(n_bnp, np.float64)
+    total = 0.0; outs = []
+    for k in range(k0, k0 + K):
+        out, tape = net_forward(net, mu, rho, bn, z, seed, step, k, sample_weights=False)
+        dout = np.zeros_like(out)
+        if loss == "mse0":
+            v, dout[0] = mse(out[0], target, 1.0 / K_total, want_grad=True)
+        elif loss == "gnll":
+            v, dout[0], dout[1] = gaussian_nll(out[0], out[1], target, 1.0 / K_total, want_grad=True)
+        else:
+            raise ValueError(loss)
+        total += v / K_total
+        g = tape.backward(dout, n_vi, n_bnp)
+        dmu += g[0]; dbn += g[2]
+        tape.free(); outs.append(out)
+    r = dict(loss=total, dmu=dmu.astype(np.float32), dbn=dbn.astype(np.float32))
+    if want_out:
+        r["out"] = np.stack(outs)
+    return r
 
 
 # ---- deterministic synthetic inputs (SURVEY.md §8d) ----------------------------------

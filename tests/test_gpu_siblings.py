@@ -1,0 +1,157 @@
+"""GPU parity of the non-Bayesian siblings (DIP, MC dropout, SGLD — bayesian_optimization.py:1064-1237,
+1447-1860) on the same HIP layer program: Dropout2d folded into the deferred BatchNorm, one-channel MSE, AdamW with decoupled
+weight decay, SGLD parameter noise.  Checked against the CPU oracle and the golden run of the reference's own skip() net."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SIB_NET = dict(input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mfvi_dip_mia_amd as M_
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    M_._lib.lib()
+    return M_
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _params(net, seed):
+    mu, _, bnp = O.init_params(net, seed)
+    _, bn, _, n_bnp = O.net_table(net)
+    g = O.normal_fill(seed, 2, 7, 0, 0, n_bnp)
+    for c, off in bn:
+        bnp[off:off + c] = 1.0 + 0.1 * g[off:off + c]; bnp[off + c:off + 2 * c] = 0.1 * g[off + c:off + 2 * c]
+    return mu, bnp
+
+
+def _engine(method, g, K=1):
+    from mfvi_dip_mia_amd.engine import SiblingEngine
+    H, W, seed = int(g["H"]), int(g["W"]), int(g["seed"])
+    kw = dict(nd=SIB_NET["nd"], nu=SIB_NET["nu"], ns=SIB_NET["ns"])
+    eng = SiblingEngine(H, W, method=method, task="den", K=K, input_depth=SIB_NET["input_depth"], lr=float(g["lr"]), seed=seed,
+                        weight_decay=float(g[method + "_wd"]), dropout_p=float(g[method + "_p"]) or 0.3, gamma=float(g[method + "_gamma"]),
+                        net_kwargs=kw, autotune=False)
+    p = float(g[method + "_p"])
+    net = O.make_net(H, W, drop_down=p, drop_up=p, **SIB_NET)
+    mu, bnp = _params(net, seed)
+    eng.mu.copy_(dev(mu)); eng.bn.copy_(dev(bnp))
+    eng.set_target(dev(O.noisy(O.phantom(H, W, seed), 0.1, seed)))
+    return eng, net, mu, bnp
+
+
+@pytest.mark.parametrize("method", ["dip", "mcd", "sgld"])
+def test_sibling_trajectory_matches_reference_golden(M, golden_dir, method):
+    g = np.load(os.path.join(golden_dir, "siblings.npz"))
+    eng, net, mu, bnp = _engine(method, g)
+    z0 = host(eng.z0)
+    assert np.array_equal(z0.ravel(), (0.1 * O.uniform_fill(int(g["seed"]), 0, 0, 0, z0.size)).astype(np.float32))
+    losses = []
+    for it in range(int(g["steps"])):
+        eng.step()
+        losses.append(eng.losses()[0])
+        if it == 0:
+            assert relerr(host(eng.out)[0], g[method + "_out0"]) < 1e-4          # the image: north_star's 1e-4 relative
+            assert relerr(host(eng.dmu), g[method + "_dmu0"]) < 2e-4 and relerr(host(eng.dbn), g[method + "_dbn0"]) < 2e-4
+            assert float(host(eng.drho).max()) == 0.0 and float(host(eng.drho).min()) == 0.0
+    gl = g[method + "_loss"]
+    assert np.abs(np.array(losses) - gl).max() < 2e-4 * np.abs(gl).max(), (losses, gl)
+    bound = 2 * int(g["steps"]) * float(g["lr"])      # sign flips of noise-floor gradients: up to lr per step in either direction
+    assert np.abs(host(eng.mu) - g[method + "_mu"]).max() < bound and np.abs(host(eng.mu) - g[method + "_mu"]).mean() < 3e-6
+    assert np.abs(host(eng.bn) - g[method + "_bn"]).max() < bound
+    assert float(host(eng.rho).max()) == 0.0                                     # RHO does not exist for these methods
+
+
+@pytest.mark.parametrize("method,loss", [("dip", "mse0"), ("mcd", "gnll")])
+def test_sibling_gradient_matches_oracle_k3(M, golden_dir, method, loss):
+    """K = 3 forwards (for MC dropout: three different mask draws, keyed by the global sample index) against the oracle."""
+    g = np.load(os.path.join(golden_dir, "siblings.npz"))
+    eng, net, mu, bnp = _engine(method, g, K=3)
+    eng.grad_only(step=5, perturb=True, with_kl=False)
+    seed = int(g["seed"])
+    z0 = host(eng.z0)
+    z = z0 + 0.1 * O.normal_fill(seed, 1, 0, 0, 5, z0.size).reshape(z0.shape)
+    r = O.sibling_grad(net, mu, bnp, z, host(eng.target), loss=loss, seed=seed, step=5, K=3, want_out=True)
+    assert relerr(host(eng.out), r["out"]) < 2e-5
+    assert abs(eng.losses()[0] - r["loss"]) < 2e-5 * abs(r["loss"])
+    assert relerr(host(eng.dmu), r["dmu"]) < 2e-4 and relerr(host(eng.dbn), r["dbn"]) < 2e-4
+    if method == "mcd":
+        a, b = host(eng.out)[0], host(eng.out)[1]
+        assert np.abs(a - b).max() > 1e-3                                        # different masks per sample
+
+
+def test_dropout_off_is_identity_and_masks_follow_the_spec(M):
+    """mfvi_plan_set_dropout(0) = nn.Dropout2d in eval mode; with dropout on, a dropped channel's BN output is beta."""
+    H = W = 16
+    P, zin, zout, names = M.skip_program(H, W, 4, 2, nd=(8,), nu=(8,), ns=(4,), drop_down=0.5, drop_up=0.5)
+    Q, _, _, _ = M.skip_program(H, W, 4, 2, nd=(8,), nu=(8,), ns=(4,))
+    seed = 3
+    net = O.make_net(H, W, input_depth=4, n_out=2, nd=(8,), nu=(8,), ns=(4,), drop_down=0.5, drop_up=0.5)
+    mu, bnp = _params(net, seed)
+    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, 4 * H * W)).reshape(4, H, W)
+    d_mu, d_bn, d_z = dev(mu), dev(bnp), dev(z)
+    rho = torch.zeros_like(d_mu)
+    plan, plain = P.compile(zin, zout, 2), Q.compile(zin, zout, 2)
+    on = host(plan.forward(d_mu, rho, d_bn, d_z, seed, 4, 1, 2, False))
+    for k in range(2):
+        ref, tape = O.net_forward(net, mu, np.zeros_like(mu), bnp, z, seed, 4, 1 + k, sample_weights=False)
+        tape.free()
+        assert relerr(on[k], ref) < 2e-5
+    M._lib.check(M._lib.lib().mfvi_plan_set_dropout(plan.handle, 0))
+    off = host(plan.forward(d_mu, rho, d_bn, d_z, seed, 4, 1, 2, False))
+    assert np.array_equal(off, host(plain.forward(d_mu, rho, d_bn, d_z, seed, 4, 1, 2, False)))
+    assert np.abs(on - off).max() > 1e-3
+
+
+def test_adamw_mse_channel_sgld_noise(M):
+    lib, L = M._lib.lib(), M._lib
+    sp = L.stream_ptr()
+    n = 5000
+    p = O.normal_fill(1, 2, 40, 0, 0, n).copy(); g_ = O.normal_fill(1, 2, 41, 0, 0, n).copy()
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    dp, dg, dm, dv = dev(p), dev(g_), dev(m), dev(v)
+    for t in (1, 2, 3):
+        L.check(lib.mfvi_adamw_step(L.ptr(dp), L.ptr(dg), L.ptr(dm), L.ptr(dv), n, 3e-3, 0.9, 0.999, 1e-8, t, 0.05, sp))
+        O.adamw(p, g_, m, v, 3e-3, t, 0.05)
+    assert np.abs(host(dp) - p).max() < 2e-6
+    # one-channel MSE with and without the SR projection
+    out = O.normal_fill(2, 2, 42, 0, 0, 2 * 3 * 16 * 24).reshape(2, 3, 16, 24)
+    for f in (1, 4):
+        tgt = O.normal_fill(2, 2, 43, 0, 0, (16 // f) * (24 // f)).reshape(16 // f, 24 // f)
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda"); dout = torch.full((2, 3, 16, 24), 7.0, device="cuda")
+        L.check(lib.mfvi_mse_channel(L.ptr(dev(out)), L.ptr(dev(tgt)), 2, 3, 16, 24, 1, f, 0.5, L.ptr(dout), L.ptr(acc), sp))
+        ref = 0.0; dref = np.zeros_like(out)
+        for k in range(2):
+            v_, d_ = O.mse(out[k, 1, ::f, ::f], tgt, 0.5, want_grad=True)
+            ref += v_; dref[k, 1, ::f, ::f] = d_
+        assert abs(float(acc) - ref) < 1e-6 * abs(ref)
+        assert np.abs(host(dout) - dref).max() < 1e-7
+    # SGLD noise: x += std * N(0,1) from RNG domain 4
+    x = O.normal_fill(3, 2, 44, 0, 0, 1001).copy(); dx = dev(x)
+    L.check(lib.mfvi_add_normal(L.ptr(dx), 9, 6, 11, 1001, 6e-4, sp))
+    assert np.abs(host(dx) - (x + np.float32(6e-4) * O.normal_fill(9, 4, 6, 0, 11, 1001))).max() < 1e-7
+    # ranged uniform fill (nn.Conv2d's kaiming-uniform bound)
+    u = torch.empty(777, device="cuda")
+    L.check(lib.mfvi_uniform_fill_range(9, 20, 0, 0, 777, -0.25, 0.25, L.ptr(u), sp))
+    assert np.abs(host(u) - (-0.25 + 0.5 * O.uniform_fill(9, 20, 0, 0, 777))).max() < 1e-7
+    assert host(u).min() >= -0.25 and host(u).max() < 0.25

@@ -223,3 +223,60 @@ def test_inpainting_ops(golden_dir):
         v, d = O.gaussian_nll_inp(o, tgt, mask, want_grad=True)
         assert abs(v - float(g[f"nll_mask{mc}"])) < 2e-5 * abs(float(g[f"nll_mask{mc}"]))
         assert relerr(d, g[f"nll_mask{mc}_dout"]) < RTOL
+
+
+SIB_NET = dict(input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+
+
+def oracle_sibling_traj(g, method, on_step0=None):
+    """The siblings' loop restated with the oracle: [add_noise] -> forward (w = mu, Dropout2d masks from the spec) -> MSE / NLL ->
+    backward -> AdamW(wd) [-> ExponentialLR].  Returns (losses, mu, bn)."""
+    H, W, steps, seed, lr0 = int(g["H"]), int(g["W"]), int(g["steps"]), int(g["seed"]), float(g["lr"])
+    p_drop, wd, gamma = float(g[method + "_p"]), float(g[method + "_wd"]), float(g[method + "_gamma"])
+    net = O.make_net(H, W, drop_down=p_drop, drop_up=p_drop, **SIB_NET)
+    conv, _, n_vi, n_bnp = O.net_table(net)
+    mu, _, bnp = _golden_params(net, seed)
+    z0 = (0.1 * O.uniform_fill(seed, 0, 0, 0, net.input_depth * H * W)).reshape(net.input_depth, H, W)
+    tgt = O.noisy(O.phantom(H, W, seed), 0.1, seed)
+    m1, v1, m2, v2 = np.zeros_like(mu), np.zeros_like(mu), np.zeros_like(bnp), np.zeros_like(bnp)
+    lr = lr0; losses = []
+    for it in range(steps):
+        if method == "sgld":
+            for lid, c in enumerate(conv):
+                n_w = int(c[0] * c[1] * c[2] * c[2]); w_off = int(c[4])
+                mu[w_off:w_off + n_w] = mu[w_off:w_off + n_w] + O.normal_fill(seed, 4, lid, 0, it, n_w) * np.float32(2 * lr0)
+        z = z0 + 0.1 * O.normal_fill(seed, 1, 0, 0, it, z0.size).reshape(z0.shape)
+        r = O.sibling_grad(net, mu, bnp, z, tgt, loss="gnll" if method == "mcd" else "mse0", seed=seed, step=it, want_out=True)
+        if it == 0 and on_step0:
+            on_step0(r)
+        losses.append(r["loss"])
+        O.adamw(mu, r["dmu"], m1, v1, lr, it + 1, wd); O.adamw(bnp, r["dbn"], m2, v2, lr, it + 1, wd)
+        if method == "sgld" and lr > 1e-8:
+            lr *= gamma
+    return np.array(losses), mu, bnp
+
+
+@pytest.mark.parametrize("method", ["dip", "mcd", "sgld"])
+def test_siblings(golden_dir, method):
+    """DIP / MC-dropout / SGLD (bayesian_optimization.py:1064-1237, 1447-1860) against the reference's skip() net with plain
+    nn.Conv2d (and its own nn.Dropout2d layers), torch AdamW(weight_decay) + ExponentialLR."""
+    g = load(golden_dir, "siblings")
+
+    def first(r):
+        assert relerr(r["out"][0], g[method + "_out0"]) < RTOL
+        assert relerr(r["dmu"], g[method + "_dmu0"]) < 1e-4 and relerr(r["dbn"], g[method + "_dbn0"]) < 1e-4
+    losses, mu, bnp = oracle_sibling_traj(g, method, first)
+    assert np.abs(losses - g[method + "_loss"]).max() < 2e-4 * np.abs(g[method + "_loss"]).max(), (losses, g[method + "_loss"])
+    # Adam moves an element whose gradient is at the fp32 noise floor by up to lr per step in either direction: the maximum is
+    # bounded by steps * lr, the mean stays tight (as in test_trajectory)
+    bound = int(g["steps"]) * float(g["lr"])
+    assert np.abs(mu - g[method + "_mu"]).max() < bound and np.abs(mu - g[method + "_mu"]).mean() < 2e-6
+    assert np.abs(bnp - g[method + "_bn"]).max() < bound
+
+
+def test_dropout_mask_spec():
+    d = O.dropout_mask(5, 3, 1, 7, 0.3, 4096)
+    assert set(np.unique(d)) == {np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(0.3))}
+    assert abs((d == 0).mean() - 0.3) < 0.03
+    assert not np.array_equal(d, O.dropout_mask(5, 3, 2, 7, 0.3, 4096))      # keyed by the sample
+    assert not np.array_equal(d, O.dropout_mask(5, 4, 1, 7, 0.3, 4096))      # ... and the step
