@@ -1,5 +1,6 @@
-"""Task runners: the reference's run_{den,sr,ct}_mfvi loops (bayesian_optimization.py:1240-1444, 2048-2263, 442-648)
-on the fused ELBO engine, producing the same artefacts (`save.npz` with the dict-of-'mfvi' object arrays that
+"""Task runners: the reference's run_{den,sr,ct,inp}_mfvi loops (bayesian_optimization.py:1240-1444, 2048-2263, 442-648, 2892-3114)
+and their non-Bayesian siblings run_{den,sr,ct}_{dip,mcd,sgld}, run_inp_{mcd,sgld} (:261-439, 651-1237, 1447-2045, 2266-2692, 3117-3544)
+on the fused engine, producing the same artefacts (`save.npz` with the dict-of-'mfvi' object arrays that
 eval_denoising.ipynb / eval_sr.ipynb / eval_ct.ipynb read, `locals.txt`).
 
 MI355X-first differences (none changes a stored number's meaning):
@@ -18,7 +19,7 @@ import time
 import numpy as np
 
 from . import _lib as L
-from .engine import ElboEngine
+from .engine import ElboEngine, SiblingEngine
 
 MC_ITER = 25            # ring-buffer length (bayesian_optimization.py:1314)
 EXP_WEIGHT = 0.99       # EMA weight (:1292)
@@ -110,17 +111,26 @@ class _Book:
         return mse_noisy, mse_gt, psnrs, ssims
 
 
+def _make_engine(method, H, W, task, K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, **kw):
+    if method == "mfvi":
+        return ElboEngine(H, W, task=task, K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=net_kwargs, **kw)
+    return SiblingEngine(H, W, method=method, task=task, K=K, input_depth=input_depth, lr=lr, seed=seed, net_kwargs=net_kwargs, **sib, **kw)
+
+
 def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, factor=4,
-         theta_step=4.0, verbose=False, net_kwargs=None, **unused):
+         theta_step=4.0, verbose=False, net_kwargs=None, method="mfvi", weight_decay=0.0, dropout_p=0.3, gamma=0.996, **unused):
     import torch
+    sib = dict(weight_decay=weight_decay, dropout_p=dropout_p, gamma=gamma)
     timestamp = str(time.time())
     run_dir = os.path.join(save_path, timestamp)
     if save:
         os.makedirs(run_dir, exist_ok=False)
         with open(os.path.join(run_dir, "locals.txt"), "w") as f:
-            for key, val in dict(task=task, img=img if not isinstance(img, np.ndarray) else "<array>", imsize=imsize, p_sigma=p_sigma,
-                                 num_iter=num_iter, lr=lr, temp=temp, sigma=sigma, input_depth=input_depth, seed=seed, show_every=show_every,
-                                 K=K, save_path=save_path).items():
+            hyper = dict(temp=temp, sigma=sigma) if method == "mfvi" else {"dip": {}, "mcd": dict(dropout_p=dropout_p, weight_decay=weight_decay),
+                                                                          "sgld": dict(gamma=gamma, weight_decay=weight_decay)}[method]
+            for key, val in dict(task=task, method=method, img=img if not isinstance(img, np.ndarray) else "<array>", imsize=imsize, p_sigma=p_sigma,
+                                 num_iter=num_iter, lr=lr, input_depth=input_depth, seed=seed, show_every=show_every,
+                                 K=K, save_path=save_path, **hyper).items():
                 print(key, "=", val, file=f)
     img_np = _load_image(img, imsize, seed)
     H, W = img_np.shape
@@ -131,15 +141,15 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
         rng = np.random.default_rng(seed + 1)
         noisy = np.clip(img_np + rng.normal(scale=p_sigma, size=img_np.shape), 0, 1).astype(np.float32)      # denoising_utils.py:11
         target = noisy
-        eng = ElboEngine(H, W, task="den", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=net_kwargs)
+        eng = _make_engine(method, H, W, "den", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib)
     elif task == "sr":
         target = np.ascontiguousarray(img_np[::factor, ::factor])    # nearest /factor decimation (:2095-2099)
         noisy = None
-        eng = ElboEngine(H, W, task="sr", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, sr_factor=factor, net_kwargs=net_kwargs)
+        eng = _make_engine(method, H, W, "sr", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, sr_factor=factor)
         extra["img_lr"] = target
     else:
         theta = np.arange(0, 180.0, theta_step, dtype=np.float32)     # :545
-        eng = ElboEngine(H, W, task="ct", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, theta_deg=theta.tolist(), net_kwargs=net_kwargs)
+        eng = _make_engine(method, H, W, "ct", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, theta_deg=theta.tolist())
         sino = torch.empty((len(theta), W), device="cuda")
         gt_d = torch.from_numpy(img_np).cuda()
         L.check(L.lib().mfvi_radon_forward(L.ptr(gt_d), L.ptr(eng.theta), 1, H, W, len(theta), L.ptr(sino), L.stream_ptr()))
@@ -162,9 +172,10 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
     torch.cuda.synchronize()
     mse_noisy, mse_gt, psnrs, ssims = book.results()
     if save:
-        wrap = lambda a: {"mfvi": a}
+        wrap = lambda a: {method: a}                                  # MSE_CORRUPTED['mfvi'] / ['dip'] / ['mcd'] / ['sgld'] of the reference
+        unc = (lambda a: {}) if method == "dip" else wrap            # run_*_dip leaves UNCERTS_EPI / UNCERTS_ALE empty (:1126-1127, :1230-1232)
         np.savez(os.path.join(run_dir, "save.npz"), img_gt=img_np, img_noisy=noisy if noisy is not None else img_np,
-                 mse_noisy=wrap(mse_noisy), mse_gt=wrap(mse_gt), recons=wrap(recons), uncerts=wrap(uncerts_epi), uncerts_ale=wrap(uncerts_ale),
+                 mse_noisy=wrap(mse_noisy), mse_gt=wrap(mse_gt), recons=wrap(recons), uncerts=unc(uncerts_epi), uncerts_ale=unc(uncerts_ale),
                  psnrs=wrap(psnrs), ssims=wrap(ssims), **extra)
         with open(os.path.join(run_dir, "locals.txt"), "a") as f:
             print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
@@ -198,8 +209,38 @@ def run_ct_mfvi(img="phantom", imsize=(256, 256), num_iter=5000, lr=3e-4, temp=4
     return _run("ct", img, imsize, 0.0, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, **kw)
 
 
+def _sibling(task, method, defaults):
+    """run_<task>_<method> with the reference's keyword names and defaults; everything else as the MFVI runner of the task."""
+    def run(img="phantom", imsize=defaults.get("imsize", (256, 256)), num_iter=5000, lr=defaults.get("lr", 3e-4), input_depth=defaults.get("input_depth", 16),
+            seed=42, show_every=100, plot=False, save=True, save_path="../logs", K=1, p_sigma=0.1, **kw):
+        hyper = {k: kw.pop(k, v) for k, v in defaults.items() if k in ("weight_decay", "dropout_p", "gamma")}
+        kw.pop("temp", None); kw.pop("sigma", None)
+        if task == "inp":
+            return run_inp_mfvi(img=img, imsize=imsize, num_iter=num_iter, lr=lr, input_depth=input_depth, seed=seed, show_every=show_every,
+                                plot=plot, save=save, save_path=save_path, K=K, method=method, **hyper, **kw)
+        return _run(task, img, imsize, p_sigma if task == "den" else 0.0, num_iter, lr, 0.0, 0.0, input_depth, seed, show_every, plot, save, save_path, K,
+                    method=method, **hyper, **kw)
+    run.__name__ = "run_%s_%s" % (task, method)
+    run.__doc__ = "bayesian_optimization.py run_%s_%s; returns the dict of results (['psnr'] is the reference's return value)." % (task, method)
+    return run
+
+
+# keyword defaults of the reference's signatures (bayesian_optimization.py:261-280, 651-670, 862-881, 1064-1083, 1447-1466, 1658-1677,
+# 1863-1883, 2266-2286, 2484-2504, 3117-3135, 3328-3346)
+run_den_dip = _sibling("den", "dip", dict())
+run_den_mcd = _sibling("den", "mcd", dict(dropout_p=0.3, weight_decay=3e-4))
+run_den_sgld = _sibling("den", "sgld", dict(gamma=0.996, weight_decay=5e-8))
+run_sr_dip = _sibling("sr", "dip", dict(imsize=(512, 512), input_depth=32))
+run_sr_mcd = _sibling("sr", "mcd", dict(imsize=(512, 512), input_depth=32, dropout_p=0.2, weight_decay=1e-4))
+run_sr_sgld = _sibling("sr", "sgld", dict(imsize=(512, 512), input_depth=32, gamma=0.996, weight_decay=1e-4))
+run_ct_dip = _sibling("ct", "dip", dict())
+run_ct_mcd = _sibling("ct", "mcd", dict(dropout_p=0.3, weight_decay=3e-4))
+run_ct_sgld = _sibling("ct", "sgld", dict(gamma=0.996, weight_decay=5e-8))
+
+
 def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=2e-3, temp=4e-6, sigma=0.01, input_depth=32, seed=42,
-                 show_every=100, plot=False, save=True, save_path="../logs", K=1, net_kwargs=None, verbose=False, **unused):
+                 show_every=100, plot=False, save=True, save_path="../logs", K=1, net_kwargs=None, verbose=False, method="mfvi",
+                 weight_decay=1e-4, dropout_p=0.2, gamma=0.996, **unused):
     """bayesian_optimization.py:2892-3114: inpainting with the 6-scale no-skip net (5x5 down filters, nearest up-sampling), sigmoid on
     the colour channels, masked Gaussian NLL.  img: (3, H, W) array in [0, 1] or 'phantom' (three synthetic planes); mask: (1|3, H, W),
     1 = known pixel (the reference ships its masks in data/inpainting/).  save.npz carries the reference's keys for this task
@@ -230,7 +271,7 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
     if mask_np.ndim == 2:
         mask_np = mask_np[None]
     num_iter += 1                                                     # bayesian_optimization.py:2935
-    eng = ElboEngine(H, W, task="inp", K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=net_kwargs)
+    eng = _make_engine(method, H, W, "inp", K, input_depth, temp, sigma, lr, seed, net_kwargs, dict(weight_decay=weight_decay, dropout_p=dropout_p, gamma=gamma))
     eng.set_target(torch.from_numpy(img_np), torch.from_numpy(mask_np))
     dev = "cuda"; HW = H * W; mc = mask_np.shape[0]
     ema = torch.zeros((4, H, W), device=dev)
@@ -274,7 +315,7 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
         psnrs = 10.0 * np.log10(1.0 / mt[:, 1:4])
     ssims = mt[:, 4:7]
     if save:
-        wrap = lambda a: {"mfvi": a}
+        wrap = lambda a: {method: a}
         np.savez(os.path.join(run_dir, "save.npz"), img_inpainting=img_np, img_mask=mask_np, mse_corrupted=wrap(mse_corrupted), mse_gt=wrap(mse_gt),
                  recons=wrap(recons), uncerts=wrap(uncerts_epi), uncerts_ale=wrap(uncerts_ale), psnrs=wrap(psnrs), ssims=wrap(ssims))
         with open(os.path.join(run_dir, "locals.txt"), "a") as f:
@@ -289,27 +330,41 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
                 recons=recons, uncerts=uncerts_epi, uncerts_ale=uncerts_ale, seconds=time.perf_counter() - t0, engine=eng)
 
 
-def load_config(path):
-    """The reference's JSON schema {bo_params:{temp:{candidates}, sigma:{candidates}}, run_params:{...}}
-    (bayesian_optimization.py:3901-3909 reads it through pandas; plain json is equivalent)."""
+run_inp_mcd = _sibling("inp", "mcd", dict(input_depth=32, lr=2e-3, dropout_p=0.2, weight_decay=1e-4))
+run_inp_sgld = _sibling("inp", "sgld", dict(input_depth=32, lr=2e-3, gamma=0.996, weight_decay=1e-4))
+
+# which two bo_params a method's candidates are (bayesian_optimization.py:3715-3718)
+BO_KEYS = {"mfvi": ("temp", "sigma"), "mcd": ("dropout_p", "weight_decay"), "sgld": ("gamma", "weight_decay"), "dip": ()}
+
+
+def load_config(path, bayes="mfvi"):
+    """The reference's JSON schema {bo_params:{<name>:{candidates}, ...}, run_params:{...}} (bayesian_optimization.py:3901-3909 reads it
+    through pandas; plain json is equivalent).  Returns ([candidate dicts], run_params)."""
     cfg = json.load(open(path))
     rp = dict(cfg["run_params"])
     for k in ("bo_results_path", "devices"):                          # eval_result.py:21-22
         rp.pop(k, None)
-    cands = [(t, s) for t in cfg["bo_params"]["temp"]["candidates"] for s in cfg["bo_params"]["sigma"]["candidates"]]
+    keys = BO_KEYS[bayes]
+    if not keys:
+        return [dict()], rp
+    a, b = keys
+    cands = [{a: x, b: y} for x in cfg["bo_params"][a]["candidates"] for y in cfg["bo_params"][b]["candidates"]]
     return cands, rp
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--task", default="denoising", choices=["denoising", "super-resolution", "ct", "inpainting"])
-    ap.add_argument("--bayes", default="mfvi", choices=["mfvi"])
+    ap.add_argument("--bayes", default="mfvi", choices=["mfvi", "dip", "mcd", "sgld"])
     ap.add_argument("--config", required=True)
     ap.add_argument("--img", default=None); ap.add_argument("--imsize", type=int, default=None)
     ap.add_argument("--k", type=int, default=1); ap.add_argument("--num-iter", type=int, default=None); ap.add_argument("--save-path", default=None)
     a = ap.parse_args(argv)
-    cands, rp = load_config(a.config)
-    fn = {"denoising": run_den_mfvi, "super-resolution": run_sr_mfvi, "ct": run_ct_mfvi, "inpainting": run_inp_mfvi}[a.task]
+    cands, rp = load_config(a.config, a.bayes)
+    short = {"denoising": "den", "super-resolution": "sr", "ct": "ct", "inpainting": "inp"}[a.task]
+    fn = globals().get("run_%s_%s" % (short, a.bayes))                # f(): bayesian_optimization.py:3709-3724
+    if fn is None:
+        raise NotImplementedError("run_%s_%s is not built" % (short, a.bayes))
     if a.img is not None:
         rp["img"] = a.img
     if a.imsize:
@@ -319,9 +374,9 @@ def main(argv=None):
     if a.save_path:
         rp["save_path"] = a.save_path
     rp["plot"] = False
-    for temp, sigma in cands:
-        r = fn(temp=temp, sigma=sigma, K=a.k, verbose=True, **rp)
-        print("temp %.3e sigma %.3e -> PSNR %.3f dB in %.1f s (%s)" % (temp, sigma, r["psnr"], r["seconds"], r["run_dir"]))
+    for cand in cands:
+        r = fn(K=a.k, verbose=True, **cand, **rp)
+        print("%s -> PSNR %.3f dB in %.1f s (%s)" % (" ".join("%s %.3e" % kv for kv in cand.items()) or "dip", r["psnr"], r["seconds"], r["run_dir"]))
 
 
 if __name__ == "__main__":

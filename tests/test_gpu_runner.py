@@ -106,3 +106,41 @@ def test_inpainting_runner_artifacts(M, tmp_path):
     rec = z["recons"].item()["mfvi"][-1]; img = z["img_inpainting"]; mk = z["img_mask"]
     psnr_np = 10 * np.log10(1.0 / np.mean((img * mk - rec * mk) ** 2))
     assert abs(psnr_np - ps[-1, 2]) < 1e-3 * abs(psnr_np)
+
+
+@pytest.mark.parametrize("method", ["dip", "mcd", "sgld"])
+def test_sibling_runner_artifacts(M, tmp_path, method):
+    """run_den_{dip,mcd,sgld} (bayesian_optimization.py:1064-1237, 1447-1860): save.npz keyed by the method name like the reference's
+    MSE_CORRUPTED['dip'] ... dicts (DIP leaves the uncertainty dicts empty); the fit moves; CLI candidates come from the method's bo_params."""
+    fn = getattr(M.runner, "run_den_" + method)
+    r = fn(img="phantom", imsize=(64, 64), num_iter=24, lr=1e-3, input_depth=16, seed=1, show_every=5, save=True, save_path=str(tmp_path), K=1)
+    z = np.load(os.path.join(r["run_dir"], "save.npz"), allow_pickle=True)
+    for key, shape in [("mse_noisy", (25,)), ("mse_gt", (25,)), ("psnrs", (25, 3)), ("ssims", (25, 3)), ("recons", (6, 1, 64, 64))]:
+        assert z[key].flat[0][method].shape == shape, key
+    if method == "dip":
+        assert z["uncerts"].flat[0] == {} and z["uncerts_ale"].flat[0] == {}
+    else:
+        assert z["uncerts"].flat[0][method].shape == (6, 1, 64, 64) and z["uncerts_ale"].flat[0][method].shape == (6, 1, 64, 64)
+    ps = z["psnrs"].flat[0][method]
+    assert np.isfinite(ps).all() and ps[-1, 2] > ps[0, 2]
+    assert r["engine"].method == method and float(r["engine"].rho.abs().max()) == 0.0
+    if method == "sgld":
+        assert abs(r["engine"].lr - 1e-3 * 0.996 ** 25) < 1e-12          # ExponentialLR stepped once per iteration
+    cands, rp = M.runner.load_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", method + "_den.json"), method)
+    assert list(cands[0]) == list(M.runner.BO_KEYS[method]) and rp["input_depth"] == 16
+
+
+def test_sibling_runners_other_tasks(M, tmp_path):
+    r = M.runner.run_ct_mcd(img="phantom", imsize=(32, 32), num_iter=3, lr=1e-3, input_depth=8, seed=1, show_every=2, save=False, net_kwargs=SMALL,
+                            dropout_p=0.1, weight_decay=1e-6)
+    assert np.isfinite(r["psnrs"]).all()
+    r = M.runner.run_sr_sgld(img="phantom", imsize=(64, 64), num_iter=3, lr=1e-3, input_depth=8, seed=1, show_every=2, save=False, net_kwargs=SMALL)
+    assert np.isfinite(r["psnrs"]).all()
+    r = M.runner.run_sr_dip(img="phantom", imsize=(64, 64), num_iter=3, lr=1e-3, input_depth=8, seed=1, show_every=2, save=False, net_kwargs=SMALL)
+    assert np.isfinite(r["psnrs"]).all()
+    r = M.runner.run_inp_mcd(img="phantom", imsize=(192, 192), num_iter=3, input_depth=8, seed=1, show_every=2, save=True, save_path=str(tmp_path),
+                             dropout_p=0.1)
+    z = np.load(os.path.join(r["run_dir"], "save.npz"), allow_pickle=True)
+    assert z["psnrs"].item()["mcd"].shape == (4, 3) and np.isfinite(z["psnrs"].item()["mcd"]).all()
+    with pytest.raises(NotImplementedError):
+        M.engine.SiblingEngine(64, 64, method="dip", task="inp")
