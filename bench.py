@@ -132,7 +132,8 @@ def main():
             sys.stderr.write("  %-22s %8.3f ms %5.1f%%\n" % (kind, ms, 100 * ms / tot))
         for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:(200 if os.environ.get('MFVI_PROFILE_FULL') else 24)]:
             c = conv_cost(eng.prog, op, eng.chunk) if op >= 0 else None
-            sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else ("all layers" if op < 0 else "concat_up")))
+            rate = "  %6.1f TFLOP/s %6.0f GB/s(alg)" % (c["flops"] / ms / 1e9, c["bytes"] / ms / 1e6) if c and ps_ in (0, 1, 2) else ""
+            sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s%s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else ("all layers" if op < 0 else "concat_up"), rate))
         sys.stderr.write("sum of kernel times in one iteration: %.3f ms\n" % tot)
 
     # forward-only rate (extra information, untimed region)

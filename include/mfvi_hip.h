@@ -139,6 +139,14 @@ int mfvi_kl_backward(const float* mu, const float* rho, int64_t n, float prior_m
 /* ---- optimizer (torch.optim.AdamW(lr, weight_decay=0): bayesian_optimization.py:1356-1357,1372) --------- */
 int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int t, void* stream);
+/* The deterministic tail of one ELBO iteration in one pass over the parameters (bayesian_optimization.py:1368-1372): kl_out = KL of all n_vi
+ * (mu, rho) pairs, grads += temp * dKL (written back), then AdamW(weight_decay = 0) on the flat blocks [MU | RHO | BN] of
+ * params / grads / m / v (2*n_vi + n_bn floats each).  Same per-element arithmetic as mfvi_kl + mfvi_kl_backward +
+ * mfvi_adam_step; the KL sum is reduced in a fixed order (bit-reproducible).  scratch: mfvi_elbo_update_scratch_bytes()
+ * bytes of device memory (per-block partial sums; contents need not be preserved between calls). */
+int64_t mfvi_elbo_update_scratch_bytes(void);
+int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma,
+                     float temp, float lr, float beta1, float beta2, float eps, int t, double* kl_out, void* scratch, void* stream);
 /* AdamW with decoupled weight decay (the SGLD sibling: bayesian_optimization.py:1765-1766): p *= 1 - lr*weight_decay first */
 int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, int t, float weight_decay, void* stream);

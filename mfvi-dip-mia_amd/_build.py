@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
 
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + os.environ.get("MFVI_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]     # e.g. -DPRODUCER_PRIO=1 for experiments
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

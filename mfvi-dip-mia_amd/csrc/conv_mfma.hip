@@ -393,7 +393,11 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             const float* __restrict__ wq = (WS ? s_w + c0 * CTP : s_w + (it & 1) * WCHUNK) + aoff;
             auto run = [&](auto steps_c) {
                 constexpr int STEPS = decltype(steps_c)::value, NQ = KK * STEPS;
-                float a[2][MF], b[2][NF];
+#ifndef MFMA_STAGES
+#define MFMA_STAGES 2
+#endif
+                constexpr int SG = MFMA_STAGES;
+                float a[SG][MF], b[SG][NF];
                 auto load = [&](int q, float (&aa)[MF], float (&bb)[NF]) {
                     const int tap = q / STEPS, st_ = q % STEPS, ky = tap / KS, kx = tap % KS;
 #pragma unroll
@@ -401,15 +405,16 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
 #pragma unroll
                     for (int f = 0; f < NF; ++f) bb[f] = FLAT ? sx[st_ * 4 * PLANE + boffk[f][ky] + kx] : sx[st_ * 4 * PLANE + boff[f] + ky * PITCH + kx];
                 };
-                load(0, a[0], b[0]);
+#pragma unroll
+                for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    if (q + 1 < NQ) load(q + 1, a[(q + 1) & 1], b[(q + 1) & 1]);
+                    if (q + SG - 1 < NQ) load(q + SG - 1, a[(q + SG - 1) % SG], b[(q + SG - 1) % SG]);
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
                         for (int f = 0; f < NF; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q & 1][i], b[q & 1][f], acc[i][f], 0, 0, 0);
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q % SG][i], b[q % SG][f], acc[i][f], 0, 0, 0);
                 }
             };
             if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});

@@ -157,6 +157,48 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- fused tail of an ELBO iteration: KL, its gradient and AdamW(wd = 0) over [MU | RHO | BN] in one pass ----
+// Same per-element arithmetic as kl_kernel / kl_bwd_kernel / adam_kernel.  The KL sum goes through per-block partials that a
+// one-block kernel adds up in block order right behind: deterministic, and no same-address atomic chain (a ticket / atomicAdd
+// per block serialises at ~70 ns each: 2048 blocks cost 150 us on MI355X).
+constexpr int ELBO_UPDATE_MAX_BLOCKS = 2048;
+struct ElboUpdateScratch { double partial[ELBO_UPDATE_MAX_BLOCKS]; };
+
+__global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          long long n_vi, long long n_bn, float m0, float s0, float temp, float b1, float b2,
+                                                          float eps, float step_size, float inv_sqrt_bc2, ElboUpdateScratch* __restrict__ sc)
+{
+    __shared__ double s_red[8];
+    const float log_s0 = logf(s0), s0sq = s0 * s0;
+    auto adam = [&](long long i, float gi) {
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    };
+    double acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vi; i += (long long)gridDim.x * 256) {
+        const float mu = p[i], r = p[n_vi + i];
+        const float s = softplus_f(r), d = mu - m0, inv = 1.f / s;
+        acc += (double)(logf(s) - log_s0) + (double)((s0sq + d * d) / (2.f * s * s)) - 0.5;
+        const float gmu = g[i] + temp * d * inv * inv;
+        const float grho = g[n_vi + i] + temp * (inv - (s0sq + d * d) * inv * inv * inv) * sigmoid_f(r);
+        g[i] = gmu; g[n_vi + i] = grho;
+        adam(i, gmu); adam(n_vi + i, grho);
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) adam(2 * n_vi + i, g[2 * n_vi + i]);
+    const double tot = block_sum_d(acc, s_red);
+    if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void elbo_update_finish_kernel(const ElboUpdateScratch* __restrict__ sc, int n_blocks, double* __restrict__ kl_out)
+{
+    __shared__ double s_red[8];
+    double t = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) t += sc->partial[b];
+    t = block_sum_d(t, s_red);
+    if (threadIdx.x == 0) *kl_out = t;
+}
+
 // ---- RNG fills ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void normal_fill_kernel(RngKey key, long long n, float a, float b, const float* __restrict__ base,
                                                           float* __restrict__ out)
@@ -504,6 +546,22 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f);
+    return (int)hipGetLastError();
+}
+
+int64_t mfvi_elbo_update_scratch_bytes(void) { return (int64_t)sizeof(ElboUpdateScratch); }
+
+int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma, float temp,
+                     float lr, float beta1, float beta2, float eps, int t, double* kl_out, void* scratch, void* stream)
+{
+    if (!params || !grads || !m || !v || !kl_out || !scratch || n_vi < 0 || n_bn < 0 || t < 1 || !(prior_sigma > 0.f)) {
+        set_error("elbo_update: bad arguments (t is 1-based, scratch of mfvi_elbo_update_scratch_bytes() bytes)"); return -1; }
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    const long long work = n_vi > n_bn ? n_vi : n_bn;
+    const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
+    hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
+                       prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (ElboUpdateScratch*)scratch);
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out);
     return (int)hipGetLastError();
 }
 

@@ -59,6 +59,7 @@ class ElboEngine:
         self.out = torch.empty((self.chunk, n_out, H, W), dtype=torch.float32, device=dev)
         self.dout = torch.empty_like(self.out)
         self.acc = torch.zeros(4, dtype=torch.float64, device=dev)        # [0] nll sum, [1] kl
+        self.upd_scratch = torch.zeros(L.lib().mfvi_elbo_update_scratch_bytes(), dtype=torch.uint8, device=dev)
         self.sr_factor = sr_factor
         self.theta = None
         if task == TASK_CT:
@@ -149,12 +150,14 @@ class ElboEngine:
                                          L.ptr(self.dmu), L.ptr(self.drho), sp))
 
     def step(self):
-        """One ELBO iteration: K forwards + NLL + backward + (all-reduce) + KL + Adam."""
+        """One ELBO iteration: K forwards + NLL + backward + (all-reduce), then KL + its gradient + Adam in one fused launch
+        (identical on every rank: no communication)."""
         lib, sp = L.lib(), L.stream_ptr()
-        self.grad_only(self.t)
+        self.grad_only(self.t, with_kl=False)
         self.t += 1
-        L.check(lib.mfvi_adam_step(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_params, self.lr,
-                                   0.9, 0.999, 1e-8, self.t, sp))
+        L.check(lib.mfvi_elbo_update(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi, self.n_bn, 0.0,
+                                     self.prior_sigma, self.temp, self.lr, 0.9, 0.999, 1e-8, self.t, L.ptr(self.acc[1:]),
+                                     L.ptr(self.upd_scratch), sp))
 
     def losses(self):
         """(nll, kl, loss) of the last grad_only/step — forces a device sync."""

@@ -155,3 +155,38 @@ def test_adamw_mse_channel_sgld_noise(M):
     L.check(lib.mfvi_uniform_fill_range(9, 20, 0, 0, 777, -0.25, 0.25, L.ptr(u), sp))
     assert np.abs(host(u) - (-0.25 + 0.5 * O.uniform_fill(9, 20, 0, 0, 777))).max() < 1e-7
     assert host(u).min() >= -0.25 and host(u).max() < 0.25
+
+
+def test_fused_elbo_update_equals_kl_plus_adam(M):
+    """mfvi_elbo_update (one launch) == mfvi_kl + mfvi_kl_backward + mfvi_adam_step: same per-element arithmetic up to the
+    compiler's fma contraction (a few ulp); the KL sum differs only in its (now fixed) summation order."""
+    lib, L = M._lib.lib(), M._lib
+    sp = L.stream_ptr()
+    n_vi, n_bn = 300_007, 1234
+    n = 2 * n_vi + n_bn
+    torch.manual_seed(3)
+    p0 = torch.cat([0.1 * torch.randn(n_vi), -3 + 0.1 * torch.randn(n_vi), 1 + 0.1 * torch.randn(n_bn)]).cuda()
+    g0 = (1e-3 * torch.randn(n)).cuda()
+    scratch = torch.zeros(lib.mfvi_elbo_update_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    pa, ga, ma, va = p0.clone(), g0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, gb, mb, vb = p0.clone(), g0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    kla = torch.zeros(1, dtype=torch.float64, device="cuda"); klb = torch.zeros_like(kla)
+    ps, temp = 1.0000110e-06, 5.6e-7
+    for t in (1, 2, 3):
+        ga.copy_(g0); gb.copy_(g0)
+        L.check(lib.mfvi_elbo_update(L.ptr(pa), L.ptr(ga), L.ptr(ma), L.ptr(va), n_vi, n_bn, 0.0, ps, temp, 1e-3, 0.9, 0.999, 1e-8, t, L.ptr(kla),
+                                     L.ptr(scratch), sp))
+        L.check(lib.mfvi_kl(L.ptr(pb), L.ptr(pb[n_vi:]), n_vi, 0.0, ps, L.ptr(klb), sp))
+        L.check(lib.mfvi_kl_backward(L.ptr(pb), L.ptr(pb[n_vi:]), n_vi, 0.0, ps, temp, L.ptr(gb), L.ptr(gb[n_vi:]), sp))
+        L.check(lib.mfvi_adam_step(L.ptr(pb), L.ptr(gb), L.ptr(mb), L.ptr(vb), n, 1e-3, 0.9, 0.999, 1e-8, t, sp))
+        close = lambda a, b: float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+        assert close(ga, gb) and close(ma, mb) and close(va, vb), t
+        assert float((pa - pb).abs().max()) < 1e-6, t                 # far below one Adam step (lr = 1e-3)
+        assert abs(float(kla) - float(klb)) < 1e-10 * abs(float(klb))      # different fp64 summation order
+    ref = O.kl(host(p0[:n_vi]), host(p0[n_vi:2 * n_vi]), ps)
+    # first-iteration KL of the oracle on the initial parameters
+    kl0 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    pc = p0.clone(); gc = g0.clone()
+    L.check(lib.mfvi_elbo_update(L.ptr(pc), L.ptr(gc), L.ptr(torch.zeros_like(p0)), L.ptr(torch.zeros_like(p0)), n_vi, n_bn, 0.0, ps, temp, 1e-3,
+                                 0.9, 0.999, 1e-8, 1, L.ptr(kl0), L.ptr(scratch), sp))
+    assert abs(float(kl0) - ref) < 2e-6 * abs(ref)
