@@ -289,8 +289,10 @@ struct BwwPart { float* base; long long stride; int max_strips; };
 int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int n_samples,
                                 hipStream_t st);
 struct GradFinEntry { long long w_off, b_off, part_off, stride; int n_w, n_b, strips, layer_id, first_block, pad; };
+// wsamp (optional): the sampled-weight slab of this pass, sample k at wsamp + k*wstride; then eps_k*softplus(rho) is read as W_k - mu
 int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
-                         int sample_weights, int n_samples, float* dmu, float* drho, hipStream_t st);
+                         int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const float* mu,
+                         hipStream_t st);
 constexpr int GRAD_FIN_QUADS = 64;      // weight quads per block of the finalize kernel
 struct FoldSrc { const float* d; long long sstride; int pad; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.

@@ -354,21 +354,39 @@ inline RngKey make_key(uint64_t seed, uint32_t domain, uint32_t stream, uint32_t
 }
 
 
+// Entry of a per-layer table that owns block `blk` (entries sorted by first_block).  The first_block column is staged in LDS with ONE
+// round of global loads: walking the table in global memory is a chain of up to n_entries dependent loads per block (~1 us each
+// under load), which dominated the table-driven kernels.  Contains a __syncthreads(): call from all threads of the block.
+constexpr int TABLE_LDS = 128;
+template <typename Entry>
+__device__ __forceinline__ int find_entry(const Entry* __restrict__ table, int n_entries, int blk, int* s_first)
+{
+    const int n_lds = min(n_entries, TABLE_LDS);
+    for (int i = threadIdx.x; i < n_lds; i += blockDim.x) s_first[i] = table[i].first_block;
+    __syncthreads();
+    int ei = 0;
+    while (ei + 1 < n_lds && s_first[ei + 1] <= blk) ++ei;
+    while (ei + 1 < n_entries && ei + 1 >= n_lds && table[ei + 1].first_block <= blk) ++ei;
+    return ei;
+}
+
 // ---------------------------------------------------------------------------------------------
 // grad_finalize: reduce the per-(strip, sample) partial dW slabs written by the MFMA backward-weight kernels of ALL layers
 // of one backward pass and apply the reparameterisation chain rule (reparam_layers.py:26-37 under autograd):
 //   d mu[j] += sum_{s,k} P[s,k,j]          d rho[j] += sigmoid(rho[j]) * sum_k eps_k[j] * sum_s P[s,k,j]
-// eps_k[j] is re-derived from the counter RNG (same key as the forward draw).  A block owns GRAD_FIN_QUADS quads of 4
+// eps_k[j] comes from the sampled-weight slab of this pass when it is still resident (wsamp != nullptr):
+//   eps_k * softplus(rho) = W_k - mu, one float4 load instead of a Philox + 2 Box-Muller evaluation per quad and sample;
+// otherwise it is re-derived from the counter RNG (same key as the forward draw).  A block owns GRAD_FIN_QUADS quads of 4
 // consecutive weights of one layer; its 4 waves split the samples and are summed through LDS.
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* __restrict__ table, int n_entries,
                                                             const float* __restrict__ part_base, const float* __restrict__ rho,
                                                             RngKey key, int sample_weights, int n_samples,
-                                                            float* __restrict__ dmu, float* __restrict__ drho)
+                                                            float* __restrict__ dmu, float* __restrict__ drho,
+                                                            const float* __restrict__ wsamp, long long wstride, const float* __restrict__ mu)
 {
     __shared__ float s_mu[3][GRAD_FIN_QUADS][4], s_rh[3][GRAD_FIN_QUADS][4];
-    int ei = 0;
-    while (ei + 1 < n_entries && table[ei + 1].first_block <= (int)blockIdx.x) ++ei;
-    const GradFinEntry e = table[ei];
+    __shared__ int s_first[TABLE_LDS];
+    const GradFinEntry e = table[find_entry(table, n_entries, (int)blockIdx.x, s_first)];
     const int t = threadIdx.x, ql = t & (GRAD_FIN_QUADS - 1), wv = t / GRAD_FIN_QUADS;
     const int item = ((int)blockIdx.x - e.first_block) * GRAD_FIN_QUADS + ql;
     const int nq_w = e.n_w >> 2, nq_b = (e.n_b + 3) >> 2;
@@ -377,13 +395,27 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
     const long long col = is_w ? 4LL * quad : (long long)e.n_w + 4LL * quad;
     const int nv = is_w ? 4 : min(4, e.n_b - 4 * quad);            // valid elements of the quad
     float am[4] = {0.f, 0.f, 0.f, 0.f}, ar[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool from_slab = sample_weights && wsamp != nullptr;
+    const long long jq = (is_w ? e.w_off : e.b_off) + 4LL * quad;      // first parameter of the quad inside MU / RHO
+    float mq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (from_slab && (is_w || is_b))
+        for (int l = 0; l < nv; ++l) mq[l] = mu[jq + l];
     if (is_w || is_b) {
         const float* __restrict__ P = part_base + e.part_off + col;
-        for (int k = wv; k < n_samples; k += 4) {
+        // the wave's samples in batches of 4, fully unrolled: the loads of a batch are independent, so up to 16 float4 are in
+        // flight per lane (one load per sample iteration left the kernel latency-bound at ~1 TB/s)
+        for (int kb = wv; kb < n_samples; kb += 16)
+#pragma unroll
+        for (int ku = 0; ku < 4; ++ku) {
+            const int k = kb + 4 * ku;
+            if (k >= n_samples) break;
             float sk[4] = {0.f, 0.f, 0.f, 0.f};
             const float* __restrict__ q0 = P + (long long)k * e.stride;
             const long long sstep = (long long)n_samples * e.stride;          // next pixel strip of the same sample
-            if (is_w) {
+            // weights and biases alike: the bias columns start at n_w (a multiple of 4) and the slab row is padded to a multiple of 4,
+            // so a bias quad is one aligned float4 too.  (A scalar loop over strips x elements for the bias quads was a chain of up to
+            // 4 x 64 x 4 dependent loads in a handful of lanes and set the duration of the whole launch: 120 us.)
+            {
                 int sidx = 0;
                 for (; sidx + 4 <= e.strips; sidx += 4) {                     // 4 independent loads in flight
                     const float4 v0 = *reinterpret_cast<const float4*>(q0 + (sidx + 0) * sstep), v1 = *reinterpret_cast<const float4*>(q0 + (sidx + 1) * sstep);
@@ -395,13 +427,20 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
                     const float4 v = *reinterpret_cast<const float4*>(q0 + sidx * sstep);
                     sk[0] += v.x; sk[1] += v.y; sk[2] += v.z; sk[3] += v.w;
                 }
-            } else {
-                for (int sidx = 0; sidx < e.strips; ++sidx)
-                    for (int l = 0; l < nv; ++l) sk[l] += q0[sidx * sstep + l];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) if (l >= nv) sk[l] = 0.f;         // padding columns of the last bias quad are never written
             }
 #pragma unroll
             for (int l = 0; l < 4; ++l) am[l] += sk[l];
-            if (sample_weights) {
+            if (from_slab) {
+                const float* __restrict__ wk = wsamp + (long long)k * wstride + jq;
+                if (is_w) {          // w_off % 4 == 0 for every layer of the slab: aligned float4
+                    const float4 w = *reinterpret_cast<const float4*>(wk);
+                    ar[0] = __builtin_fmaf(sk[0], w.x - mq[0], ar[0]); ar[1] = __builtin_fmaf(sk[1], w.y - mq[1], ar[1]);
+                    ar[2] = __builtin_fmaf(sk[2], w.z - mq[2], ar[2]); ar[3] = __builtin_fmaf(sk[3], w.w - mq[3], ar[3]);
+                } else
+                    for (int l = 0; l < nv; ++l) ar[l] = __builtin_fmaf(sk[l], wk[l] - mq[l], ar[l]);
+            } else if (sample_weights) {
                 RngKey kw = key; kw.sample += (uint32_t)k;
                 kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id + (is_w ? 0 : 1));
                 float z[4]; spec_normal4(kw, (uint32_t)quad, z);
@@ -423,7 +462,10 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
         const long long j0 = (is_w ? e.w_off : e.b_off) + 4LL * quad;
         for (int l = 0; l < nv; ++l) {
             dmu[j0 + l] += am[l];
-            if (sample_weights) drho[j0 + l] += ar[l] * sigmoid_f(rho[j0 + l]);
+            if (from_slab) {         // ar = sum_k dW_k * (W_k - mu) = softplus(rho) * sum_k dW_k * eps_k, with the softplus the draw used
+                const float r = rho[j0 + l], sp = is_w ? softplus_fast(r) : softplus_f(r);
+                drho[j0 + l] += ar[l] / sp * sigmoid_f(r);
+            } else if (sample_weights) drho[j0 + l] += ar[l] * sigmoid_f(rho[j0 + l]);
         }
     }
 }
@@ -438,9 +480,8 @@ __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* 
                                                              const float* __restrict__ mu, const float* __restrict__ rho,
                                                              RngKey key, float* __restrict__ wsamp, long long wstride)
 {
-    int ei = 0;
-    while (ei + 1 < n_entries && table[ei + 1].first_block <= (int)blockIdx.x) ++ei;
-    const SampleEntry e = table[ei];
+    __shared__ int s_first[TABLE_LDS];
+    const SampleEntry e = table[find_entry(table, n_entries, (int)blockIdx.x, s_first)];
     const int k = blockIdx.y;
     const int item = ((int)blockIdx.x - e.first_block) * SAMPLE_QUADS + (int)threadIdx.x;
     const int nq_w = e.n_w >> 2, nq_b = (e.n_b + 3) >> 2;
@@ -486,11 +527,12 @@ int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blo
 }
 
 int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
-                         int sample_weights, int n_samples, float* dmu, float* drho, hipStream_t st)
+                         int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const float* mu,
+                         hipStream_t st)
 {
     if (n_entries < 1 || n_blocks < 1) return 0;
     hipLaunchKernelGGL(grad_finalize_kernel, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
-                       n_samples, dmu, drho);
+                       n_samples, dmu, drho, wsamp, wstride, mu);
     return (int)hipGetLastError();
 }
 

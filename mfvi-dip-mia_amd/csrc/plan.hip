@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -293,6 +294,15 @@ bool use_mfma()
     return on;
 }
 
+// MFVI_GRAD_FROM_SLAB=1: grad_finalize reads eps * softplus(rho) as W_k - mu from the sampled-weight slab instead of re-deriving eps
+// from the counter RNG.  Measured slower on MI355X (87 vs 72 us: the extra 66 MB of loads cost more than the Philox work they save),
+// kept as an A/B switch.
+bool grad_from_slab()
+{
+    static const bool on = [] { const char* e = getenv("MFVI_GRAD_FROM_SLAB"); return e && e[0] == '1'; }();
+    return on;
+}
+
 RngKey base_key(uint64_t seed, uint32_t step, uint32_t k0)
 {
     RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = 0; k.sample = k0; k.step = step; return k;
@@ -458,14 +468,21 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
         if (rc) { if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc)); return rc; }
     }
     if (!fin.empty()) {
+        // longest blocks first: a block's work grows with the number of pixel strips of its layer
+        std::stable_sort(fin.begin(), fin.end(), [](const GradFinEntry& a, const GradFinEntry& b) { return a.strips > b.strips; });
+        fin_blocks = 0;
+        for (auto& e : fin) { e.first_block = fin_blocks; fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS; }
         ProfScope ps(plan, -1, PASS_GRAD_FINALIZE, st);
         const bool same = fin.size() == plan->fin_uploaded.size() && memcmp(fin.data(), plan->fin_uploaded.data(), sizeof(GradFinEntry) * fin.size()) == 0;
         if (!same) {      // tilings change only when the plan is (re)tuned: the table is uploaded once in steady state
+            if (getenv("MFVI_DEBUG_FIN")) for (auto& e : fin) fprintf(stderr, "fin layer %d n_w %d strips %d first_block %d\n", e.layer_id, e.n_w, e.strips, e.first_block);
             const hipError_t e = hipMemcpyAsync(plan->fin_dev, fin.data(), sizeof(GradFinEntry) * fin.size(), hipMemcpyHostToDevice, st);
             if (e != hipSuccess) { set_error("backward: gradient table upload failed: %s", hipGetErrorString(e)); return (int)e; }
             plan->fin_uploaded = fin;
         }
-        const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho, key, sample_weights, n_samples, dmu, drho, st);
+        // every layer of `fin` (MFMA backward-weight) is also in the sampling table (same shape conditions), so its W_k sit in the slab
+        const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho, key, sample_weights, n_samples, dmu, drho,
+                                            presample && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu, st);
         if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     if (plan->n_entries) {
