@@ -38,11 +38,20 @@ constexpr int EPP = 36;                 // row pitch of the per-wave output tran
 
 constexpr int pitch16(int n) { return ((n + 15) / 32) * 32 + 16; }      // smallest p >= n with p % 32 == 16
 
-template <int KS, int STRIDE, int MF, int TH>
+template <int KS, int STRIDE, int MF, int TH, bool BIGC = false>
 struct MCfg {
     static constexpr int TW = 32;
     static constexpr int CT = 16 * MF;
-    static constexpr int CC = 8;                                   // reduction channels per activation stage
+    // Reduction channels per activation stage.  A stage costs one barrier and (with the one-stage register prefetch) about one
+    // global-load latency; a 1x1 convolution has so little matrix work per 8 channels (2 k-steps) that its loop ran at
+    // latency x Cin/8 (26 us for 128 -> 4 channels on a 16x16 map).  Its windows are small (no halo), so with BIGC it stages 32
+    // (16 for 16-row tiles) channels at a time: a quarter of the iterations, four times the bytes in flight per lane.  The 70 KB
+    // of LDS halve the blocks per CU, which costs the bandwidth-bound 16/32-channel layers at 128^2 / 256^2 more than it saves:
+    // BIGC is used from 64 reduction channels up.
+#ifndef MFVI_CC1
+#define MFVI_CC1 32
+#endif
+    static constexpr int CC = (KS == 1 && BIGC) ? (TH >= 16 ? MFVI_CC1 / 2 : MFVI_CC1) : 8;
     static constexpr int NF = TH / 2;                              // pixel fragments per wave (TH/4 rows x 2 halves)
     static constexpr int KK = KS * KS;
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
@@ -74,10 +83,10 @@ struct MfmaArgs {
 // FLAT: for narrow output domains (<= ~66 wide) a tile is `rt` FULL rows of the domain, its TH*32 pixels dealt to the MFMA
 // fragments in row-major order, instead of a TH x 32 rectangle: a 34-wide padded-gradient domain then fills 99% of the
 // fragments (2 x 32-pixel tile columns fill 53%).  The staged window keeps the same LDS plane with a run-time pitch.
-template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT>
-__global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1))) void conv_mfma_kernel(MfmaArgs A)
+template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false>
+__global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
 {
-    using Cfg = MCfg<KS, STRIDE, MF, TH>;
+    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
     constexpr int WCHUNK = KK * CC * CTP;               // floats of one weight chunk (non-WS double buffer)
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
             //      so the LDS reads of step q+1 are in flight while the matrix core runs step q ----
             const float* __restrict__ sx = s_x[it & 1];
             const float* __restrict__ wq = (WS ? s_w + c0 * CTP : s_w + (it & 1) * WCHUNK) + aoff;
-            auto run = [&](auto steps_c) {
+            auto run = [&](auto steps_c, int sbase) {          // STEPS 4-channel steps of the chunk, starting at step sbase
                 constexpr int STEPS = decltype(steps_c)::value, NQ = KK * STEPS;
 #ifndef MFMA_STAGES
 #define MFMA_STAGES 2
@@ -401,9 +410,9 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                 auto load = [&](int q, float (&aa)[MF], float (&bb)[NF]) {
                     const int tap = q / STEPS, st_ = q % STEPS, ky = tap / KS, kx = tap % KS;
 #pragma unroll
-                    for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + st_ * 4 * CTP + i * 16];
+                    for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + (sbase + st_) * 4 * CTP + i * 16];
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) bb[f] = FLAT ? sx[st_ * 4 * PLANE + boffk[f][ky] + kx] : sx[st_ * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                    for (int f = 0; f < NF; ++f) bb[f] = FLAT ? sx[(sbase + st_) * 4 * PLANE + boffk[f][ky] + kx] : sx[(sbase + st_) * 4 * PLANE + boff[f] + ky * PITCH + kx];
                 };
 #pragma unroll
                 for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG]);
@@ -417,7 +426,14 @@ __global__ __launch_bounds__(512, (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))
                             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q % SG][i], b[q % SG][f], acc[i][f], 0, 0, 0);
                 }
             };
-            if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
+            if constexpr (CC == 8) {
+                if (cc4 == 8) run(std::integral_constant<int, 2>{}, 0); else run(std::integral_constant<int, 1>{}, 0);
+            } else {      // 1x1: whole stages fully unrolled, the ragged last stage in halves
+                int sb = 0, left = cc4 >> 2;
+                if (left == CC / 4) { run(std::integral_constant<int, CC / 4>{}, 0); left = 0; }
+                for (; left >= 4; left -= 4, sb += 4) run(std::integral_constant<int, 4>{}, sb);
+                for (; left >= 1; left -= 1, sb += 1) run(std::integral_constant<int, 1>{}, sb);
+            }
 
             if (ci == n_chunks - 1) {
                 // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg.
@@ -628,19 +644,24 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             A.n_tiles = (OH + rt - 1) / rt;                                                                                \
         }                                                                                                                  \
         const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
-        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP, ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * Cfg::CTP; \
+        constexpr bool CAN_BIG = KS == 1 && !(FL_);                                                                        \
+        const bool big = CAN_BIG && RED >= 64;                                                                             \
+        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP,                                              \
+                     ck_bytes = 2 * sizeof(float) * (size_t)KK * (big ? MCfg<KS, STRIDE, MF_, TH_, CAN_BIG>::CC : Cfg::CC) * Cfg::CTP; \
         const long long nb = (long long)A.n_tiles * my * n_samples;                                                        \
         int T = (int)(nb / 512); T = T < 1 ? 1 : (T > 8 ? 8 : T);                                                          \
         if (forced_T > 0) T = forced_T;                                                                                    \
         if (T >= 2 && ws_bytes <= 40 * 1024) {                                                                             \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
         } else {                                                                                                           \
             if (forced_T > 1) return -3;                                                                                   \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
-            hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }
