@@ -47,11 +47,12 @@ struct MCfg {
     // latency x Cin/8 (26 us for 128 -> 4 channels on a 16x16 map).  Its windows are small (no halo), so with BIGC it stages 32
     // (16 for 16-row tiles) channels at a time: a quarter of the iterations, four times the bytes in flight per lane.  The 70 KB
     // of LDS halve the blocks per CU, which costs the bandwidth-bound 16/32-channel layers at 128^2 / 256^2 more than it saves:
-    // BIGC is used from 64 reduction channels up.
+    // BIGC is used from 64 reduction channels up.  The same holds for 3x3 layers on the 8x8 ... 32x32 maps at the bottom of the
+    // hour-glass (FLAT tiles of 2 or 4 rows, 64-132 channels = 8-17 stages of 18 k-steps): they stage 32 channels with BIGC too.
 #ifndef MFVI_CC1
 #define MFVI_CC1 32
 #endif
-    static constexpr int CC = (KS == 1 && BIGC) ? (TH >= 16 ? MFVI_CC1 / 2 : MFVI_CC1) : 8;
+    static constexpr int CC = !BIGC ? 8 : (KS == 1 ? (TH >= 16 ? MFVI_CC1 / 2 : MFVI_CC1) : 32);
     static constexpr int NF = TH / 2;                              // pixel fragments per wave (TH/4 rows x 2 halves)
     static constexpr int KK = KS * KS;
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
@@ -428,11 +429,15 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             };
             if constexpr (CC == 8) {
                 if (cc4 == 8) run(std::integral_constant<int, 2>{}, 0); else run(std::integral_constant<int, 1>{}, 0);
-            } else {      // 1x1: whole stages fully unrolled, the ragged last stage in halves
+            } else if constexpr (KS == 1) {      // big stages of a 1x1 layer: one tap, so any grouping keeps the channel order of the sum
                 int sb = 0, left = cc4 >> 2;
                 if (left == CC / 4) { run(std::integral_constant<int, CC / 4>{}, 0); left = 0; }
                 for (; left >= 4; left -= 4, sb += 4) run(std::integral_constant<int, 4>{}, sb);
                 for (; left >= 1; left -= 1, sb += 1) run(std::integral_constant<int, 1>{}, sb);
+            } else {      // big stages of a 3x3 layer: 8 channels at a time, taps inside — the accumulation order of the 8-channel stages
+                int sb = 0, left = cc4 >> 2;
+                for (; left >= 2; left -= 2, sb += 2) run(std::integral_constant<int, 2>{}, sb);
+                if (left) run(std::integral_constant<int, 1>{}, sb);
             }
 
             if (ci == n_chunks - 1) {
@@ -644,20 +649,26 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             A.n_tiles = (OH + rt - 1) / rt;                                                                                \
         }                                                                                                                  \
         const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
-        constexpr bool CAN_BIG = KS == 1 && !(FL_);                                                                        \
-        const bool big = CAN_BIG && RED >= 64;                                                                             \
-        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP,                                              \
-                     ck_bytes = 2 * sizeof(float) * (size_t)KK * (big ? MCfg<KS, STRIDE, MF_, TH_, CAN_BIG>::CC : Cfg::CC) * Cfg::CTP; \
+        constexpr bool CAN_BIG = (KS == 1 && !(FL_)) || (KS == 3 && STRIDE == 1 && MODE == 0 && (FL_) && TH_ <= 4);   /* backward-data stages two tensors: measured slower with big stages */ \
+        using BigCfg = MCfg<KS, STRIDE, MF_, TH_, CAN_BIG>;                                                                \
+        bool big = CAN_BIG && RED >= 64;                                                                                   \
+        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP;                                              \
+        const size_t ck_big = 2 * sizeof(float) * (size_t)KK * BigCfg::CC * Cfg::CTP;                                      \
+        const size_t lds_big = 2 * sizeof(float) * (size_t)BigCfg::X_FLOATS + 24 * 1024;   /* static LDS of the big-stage variant */ \
+        size_t ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * Cfg::CTP;                                             \
         const long long nb = (long long)A.n_tiles * my * n_samples;                                                        \
         int T = (int)(nb / 512); T = T < 1 ? 1 : (T > 8 ? 8 : T);                                                          \
         if (forced_T > 0) T = forced_T;                                                                                    \
         if (T >= 2 && ws_bytes <= 40 * 1024) {                                                                             \
+            if (lds_big + ws_bytes > 150 * 1024) big = false;                                                              \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
             if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
         } else {                                                                                                           \
             if (forced_T > 1) return -3;                                                                                   \
+            if (lds_big + ck_big > 150 * 1024) big = false;                                                                \
+            if (big) ck_bytes = ck_big;                                                                                    \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
             if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
