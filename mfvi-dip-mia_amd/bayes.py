@@ -99,6 +99,7 @@ class MeanFieldVI(nn.Module):
         self._token = 0
         self._plans = {}
         self._sampling = True
+        self._drops = [m for m in net.modules() if isinstance(m, nn.Dropout2d)]
         self._replace(net, prior, posteriors, kl_type)
         self._flatten(posteriors)
         self.net = net.to(device) if False else net          # parameters already live on `device` (flat buffer)
@@ -234,7 +235,7 @@ class MeanFieldVI(nn.Module):
                 if v['pad'] or v['up']:
                     fail("ReflectionPad2d after a pending pad/upsample")
                 return dict(v, pad=p[0])
-            if isinstance(m, Conv2dRT):
+            if isinstance(m, (Conv2dRT, nn.Conv2d)):
                 if m is not next(vi_iter):
                     fail("conv execution order differs from module order")
                 k = m.kernel_size[0]
@@ -242,13 +243,22 @@ class MeanFieldVI(nn.Module):
                     fail("Conv2d must follow ReflectionPad2d(k//2)")
                 if k not in (1, 3, 5):
                     fail("kernel size %d (1, 3, 5 are built)" % k)
-                stride = m.kwargs['stride'][0] if isinstance(m.kwargs['stride'], (tuple, list)) else m.kwargs['stride']
+                stride = m.kwargs['stride'] if isinstance(m, Conv2dRT) else m.stride
+                stride = stride[0] if isinstance(stride, (tuple, list)) else stride
                 out = P.tensor(m.out_channels, *P.conv_out_hw(v['tid'], k, stride))
                 P.conv(v['tid'], out, k, stride, bias=m._has_bias)
                 lay = P.layers[-1]
                 if lay['w_off'] != m._w_off or lay['b_off'] != m._b_off:
                     fail("internal: parameter offsets out of sync")
-                return dict(tid=out, pad=0, up=None)
+                return dict(tid=out, pad=0, up=None, fresh_conv=True)
+            if isinstance(m, nn.Dropout2d):
+                # models/common.py:125-131: conv -> Dropout2d -> (BatchNorm): folded into the BatchNorm that follows the conv output
+                if not v.get('fresh_conv') or v['pad'] or v['up']:
+                    fail("Dropout2d must directly follow a convolution")
+                if m.inplace:
+                    fail("in-place Dropout2d")
+                P.set_dropout(v['tid'], float(m.p))
+                return dict(v, fresh_conv=False)
             if isinstance(m, nn.BatchNorm2d):
                 v = flush_up(v)
                 if v['pad']:
@@ -256,7 +266,7 @@ class MeanFieldVI(nn.Module):
                 P.set_bn(v['tid'], act=False, eps=m.eps)
                 if P.bns[-1]['off'] != m._bn_off:
                     fail("internal: BatchNorm offsets out of sync")
-                return v
+                return dict(v, fresh_conv=False)
             if isinstance(m, nn.LeakyReLU):
                 t = P.tensors[v['tid']]
                 if not t['has_bn'] or t['has_act'] or v['pad'] or v['up']:
@@ -272,6 +282,9 @@ class MeanFieldVI(nn.Module):
             fail(type(m).__name__)
 
         res = run(self.net, dict(tid=zin, pad=0, up=None))
+        for t in P.tensors:
+            if t["drop_p"] > 0 and not t["has_bn"]:
+                fail("Dropout2d without a BatchNorm behind it")
         if res['pad'] or res['up'] or P.tensors[res['tid']]['has_bn']:
             fail("the net must end with a convolution")
         if P.n_vi != self.n_vi or P.n_bn != self.n_bn:
@@ -331,10 +344,13 @@ class MeanFieldVI(nn.Module):
             plan.autotune(mu, rho, bn, x3, self.n_samples)
         sample = bool(self.training and self._sampling)
         step = self._step
+        dropping = any(d.training for d in self._drops)      # nn.Dropout2d is the identity in eval mode
+        if self._drops:
+            L.check(L.lib().mfvi_plan_set_dropout(plan.handle, int(dropping)))
         out = plan.forward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, sample)
         self._token += 1
-        if sample:
-            self._step += 1                  # fresh eps for every call, like randn_like in VIModule.rsample
+        if sample or dropping:
+            self._step += 1                  # fresh eps / dropout masks for every call, like randn_like in VIModule.rsample
         return out, (self._token, plan, x3, step, sample)
 
     def _hip_backward(self, token, dout, want_dz):
@@ -384,6 +400,150 @@ class MeanFieldVI(nn.Module):
                 c = m.out_channels
                 grads += [g[m._b_off:m._b_off + c], g[n + m._b_off:n + m._b_off + c]]
         return grads
+
+
+class FusedNet(MeanFieldVI):
+    """The reference's PLAIN skip() nets — what run_*_dip / run_*_mcd / run_*_sgld optimise (bayesian_optimization.py:1140-1166,
+    1526-1567, 1739-1766) — executed by the same HIP layer program: nn.Conv2d weights are used as they are (w = weight, no
+    sampling, no rho), nn.Dropout2d layers of the MC-dropout nets are folded into the BatchNorm that follows them.
+
+        net = FusedNet(get_net(input_depth, 'skip', pad, ..., dropout_mode_down='2d', dropout_p_down=p, ...), device=device)
+        out = net(net_input); loss = mse(out[:, :1], target); loss.backward(); optimizer.step()
+
+    The reference runs these nets as ordinary torch modules, so this wrapper is the one extra line a caller adds; parameters keep
+    the reference's names below the `net.` prefix (net.<path>.weight / .bias and the BatchNorm keys) and are views of one flat buffer."""
+
+    def __init__(self, net, device=torch.device('cuda'), seed=None, n_samples=1):
+        nn.Module.__init__(self)
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise NotImplementedError("this implementation runs on the GPU only (device=%s); there is no CPU path" % device)
+        L.lib()
+        self.device = device
+        self.net = net
+        self.n_samples = int(n_samples)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 63) - 1)
+        self._step = 0
+        self._token = 0
+        self._plans = {}
+        self._sampling = False                                   # w = weight: RTLayer's eval branch of the kernels
+        self._drops = [m for m in net.modules() if isinstance(m, nn.Dropout2d)]
+        for m in net.modules():
+            if isinstance(m, (nn.Linear, nn.Conv3d, nn.Dropout)) and not isinstance(m, nn.Dropout2d):
+                raise NotImplementedError("%s is outside the skip() family" % type(m).__name__)
+        self._flatten(None)
+
+    def _flatten(self, posteriors):
+        """Conv weights / biases become views of the MU block of one flat fp32 buffer [MU | RHO (unused, zero) | BN]; the values
+        nn.Conv2d initialised them with (kaiming-uniform) are kept."""
+        self._vi = [m for m in self.net.modules() if isinstance(m, nn.Conv2d)]
+        self._bn = [m for m in self.net.modules() if isinstance(m, nn.BatchNorm2d)]
+        n_vi = 0
+        for m in self._vi:
+            if m.groups != 1 or m.dilation != (1, 1) or m.padding != (0, 0):
+                raise NotImplementedError("Conv2d with groups/dilation/own padding is outside the skip() family")
+            kh, kw = m.kernel_size
+            m._has_bias = m.bias is not None
+            m._w_off = n_vi; n_vi += m.out_channels * m.in_channels * kh * kw
+            m._b_off = -1
+            if m._has_bias:
+                m._b_off = n_vi; n_vi += m.out_channels
+        n_bn = sum(2 * b.num_features for b in self._bn)
+        self.n_vi, self.n_bn = n_vi, n_bn
+        flat = torch.zeros(2 * n_vi + n_bn, dtype=torch.float32, device=self.device)
+        self._flat = flat
+        self._fill(flat, lambda m: m.weight.data, lambda m: m.bias.data, lambda b: (b.weight.data, b.bias.data))
+        self._rebind(flat)
+        for b in self._bn:
+            if not b.affine:
+                raise NotImplementedError("non-affine BatchNorm")
+            b.to(self.device)
+            self._rebind_bn(flat, b)
+        self._param_list = []
+        for m in self._vi:
+            self._param_list += [m.weight] + ([m.bias] if m._has_bias else [])
+        for b in self._bn:
+            self._param_list += [b.weight, b.bias]
+
+    def _fill(self, flat, w_of, b_of, bn_of):
+        off = 0
+        for m in self._vi:
+            nw = m.weight.numel()
+            flat[m._w_off:m._w_off + nw] = w_of(m).reshape(-1).to(flat)
+            if m._has_bias:
+                flat[m._b_off:m._b_off + m.out_channels] = b_of(m).to(flat)
+        for b in self._bn:
+            c = b.num_features; o = 2 * self.n_vi + off
+            g, be = bn_of(b)
+            flat[o:o + c] = g.to(flat); flat[o + c:o + 2 * c] = be.to(flat)
+            b._bn_off = off
+            off += 2 * c
+
+    def _rebind(self, flat):
+        for m in self._vi:
+            nw = m.weight.numel()
+            w = flat[m._w_off:m._w_off + nw].view(m.out_channels, m.in_channels, *m.kernel_size)
+            if isinstance(m.weight, nn.Parameter) and m.weight.device == flat.device:
+                m.weight.data = w
+            else:
+                m.weight = nn.Parameter(w)
+            if m._has_bias:
+                bv = flat[m._b_off:m._b_off + m.out_channels]
+                if isinstance(m.bias, nn.Parameter) and m.bias.device == flat.device:
+                    m.bias.data = bv
+                else:
+                    m.bias = nn.Parameter(bv)
+
+    def _rebind_bn(self, flat, b):
+        c = b.num_features; o = 2 * self.n_vi + b._bn_off
+        b.weight.data = flat[o:o + c]; b.bias.data = flat[o + c:o + 2 * c]
+
+    def _views_intact(self):
+        base = self._flat.data_ptr()
+        m = self._vi[-1]
+        ok = m.weight.data_ptr() == base + 4 * m._w_off
+        if self._bn:
+            b = self._bn[-1]
+            ok = ok and b.weight.data_ptr() == base + 4 * (2 * self.n_vi + b._bn_off)
+        return ok
+
+    def _reflatten(self):
+        new = torch.zeros_like(self._flat)
+        self._fill(new, lambda m: m.weight.data, lambda m: m.bias.data, lambda b: (b.weight.data, b.bias.data))
+        self._flat = new
+        self._rebind(new)
+        for b in self._bn:
+            self._rebind_bn(new, b)
+
+    def kl(self):
+        raise AttributeError("FusedNet wraps a deterministic net: there is no KL term (use MeanFieldVI for the Bayesian path)")
+
+    def set_sampling(self, enabled=True):
+        if enabled:
+            raise ValueError("a deterministic net has nothing to sample")
+        return self
+
+    def _hip_backward(self, token, dout, want_dz):
+        tok, plan, x3, step, sample = token
+        if tok != self._token:
+            raise RuntimeError("backward through a forward that is no longer the latest one: the activations live in one workspace per plan")
+        mu, rho, bn = self._blocks()
+        g = torch.zeros(2 * self.n_vi + max(self.n_bn, 1), dtype=torch.float32, device=self.device)
+        n = self.n_vi
+        dz = torch.empty((self.n_samples,) + tuple(x3.shape), device=self.device) if want_dz else None
+        plan.backward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, dout, g[:n], g[n:2 * n], g[2 * n:], False, dz=dz)
+        grads = []
+        for m in self._vi:
+            nw = m.weight.numel()
+            grads.append(g[m._w_off:m._w_off + nw].view_as(m.weight))
+            if m._has_bias:
+                grads.append(g[m._b_off:m._b_off + m.out_channels])
+        for b in self._bn:
+            c = b.num_features; o = 2 * n + b._bn_off
+            grads += [g[o:o + c], g[o + c:o + 2 * c]]
+        if want_dz:
+            dz = dz.sum(0, keepdim=True) if dz.shape[0] > 1 else dz
+        return grads, dz
 
 
 def gaussian_nll(mu, neg_logvar, target, reduction='mean'):

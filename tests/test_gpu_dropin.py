@@ -121,3 +121,73 @@ def test_k_samples_in_one_call_and_errors(M):
         M.MeanFieldVI(mk(), prior={'mu': 0, 'sigma': 0.1, 'pi': 0.5}, device=device, reparam='')
     with pytest.raises(NotImplementedError):
         net.eval(); net(x)
+
+
+@pytest.mark.parametrize("method", ["dip", "mcd", "sgld"])
+def test_fusednet_plain_nets_follow_the_reference_loops(M, golden_dir, method):
+    """The reference's calling sequence for its non-Bayesian runs (bayesian_optimization.py:1140-1181 DIP, 1526-1581 MC dropout,
+    1739-1786 SGLD) on the drop-in classes: get_net(...) [with the '2d' dropout options] -> FusedNet -> torch AdamW / ExponentialLR,
+    add_noise by re-assigning .data.  Checked against the golden run of the reference's own modules (tests/golden/siblings.npz)."""
+    import torch.nn.functional as F
+    g = np.load(os.path.join(golden_dir, "siblings.npz"))
+    H, W, seed, lr, steps = int(g["H"]), int(g["W"]), int(g["seed"]), float(g["lr"]), int(g["steps"])
+    p, wd, gamma = float(g[method + "_p"]), float(g[method + "_wd"]), float(g[method + "_gamma"])
+    mode = '2d' if p else 'None'
+    net = M.get_net(8, 'skip', 'reflection', 'bilinear', n_channels=2, skip_n33d=[8, 16, 16], skip_n33u=[8, 16, 16], skip_n11=4, num_scales=3,
+                    dropout_mode_down=mode, dropout_p_down=p, dropout_mode_up=mode, dropout_p_up=p)
+    net = M.FusedNet(net, device=torch.device('cuda'), seed=seed)
+    onet = O.make_net(H, W, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    mu, _, bnp = O.init_params(onet, seed)
+    gg = O.normal_fill(seed, 2, 7, 0, 0, n_bnp)
+    for c, off in bn:
+        bnp[off:off + c] = 1.0 + 0.1 * gg[off:off + c]; bnp[off + c:off + 2 * c] = 0.1 * gg[off + c:off + 2 * c]
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    with torch.no_grad():
+        for m, r in zip(convs, conv):
+            cin, cout, k, s_, wo, bo = [int(v) for v in r]
+            m.weight.copy_(torch.from_numpy(mu[wo:wo + cout * cin * k * k].reshape(cout, cin, k, k))); m.bias.copy_(torch.from_numpy(mu[bo:bo + cout]))
+        for m, (c, off) in zip(bns, bn):
+            c, off = int(c), int(off)
+            m.weight.copy_(torch.from_numpy(bnp[off:off + c])); m.bias.copy_(torch.from_numpy(bnp[off + c:off + 2 * c]))
+    assert [k for k in net.state_dict() if "Conv2d" in k][:2] == ["net.Concat_up_5.0.Sequential_skip_1.Conv2d_skip_1.weight",
+                                                                  "net.Concat_up_5.0.Sequential_skip_1.Conv2d_skip_1.bias"]
+    z0 = (0.1 * O.uniform_fill(seed, 0, 0, 0, 8 * H * W)).reshape(1, 8, H, W)
+    tgt = torch.from_numpy(O.noisy(O.phantom(H, W, seed), 0.1, seed))[None, None].cuda()
+    opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=wd)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=gamma) if method == "sgld" else None
+    losses = []
+    for it in range(steps):
+        opt.zero_grad()
+        if method == "sgld":                      # add_noise(net, 2, LR) (bayesian_optimization.py:166-170) with the spec's noise
+            for lid, m in enumerate(convs):
+                nz = torch.from_numpy(O.normal_fill(seed, 4, lid, 0, it, m.weight.numel()).reshape(tuple(m.weight.shape))).cuda()
+                m.weight.data = m.weight.data + nz * 2 * lr
+        z = torch.from_numpy(z0 + 0.1 * O.normal_fill(seed, 1, 0, 0, it, z0.size).reshape(z0.shape)).cuda()
+        out = net(z)
+        loss = M.gaussian_nll(out[:, :1], out[:, 1:], tgt) if method == "mcd" else F.mse_loss(out[:, :1], tgt)
+        loss.backward()
+        if it == 0:
+            assert relerr(out.detach().cpu().numpy()[0], g[method + "_out0"]) < 1e-4
+            gmu = np.zeros(n_vi, np.float32)
+            for m, r in zip(convs, conv):
+                cin, cout, k, s_, wo, bo = [int(v) for v in r]
+                gmu[wo:wo + cout * cin * k * k] = m.weight.grad.cpu().numpy().ravel(); gmu[bo:bo + cout] = m.bias.grad.cpu().numpy()
+            assert relerr(gmu, g[method + "_dmu0"]) < 2e-4
+        opt.step()
+        if sched is not None and sched.get_last_lr()[0] > 1e-8:
+            sched.step()
+        losses.append(float(loss))
+    gl = g[method + "_loss"]
+    assert np.abs(np.array(losses) - gl).max() < 2e-4 * np.abs(gl).max(), (losses, gl)
+    fmu = np.zeros(n_vi, np.float32)
+    for m, r in zip(convs, conv):
+        cin, cout, k, s_, wo, bo = [int(v) for v in r]
+        fmu[wo:wo + cout * cin * k * k] = m.weight.detach().cpu().numpy().ravel(); fmu[bo:bo + cout] = m.bias.detach().cpu().numpy()
+    assert np.abs(fmu - g[method + "_mu"]).max() < 2 * steps * lr and np.abs(fmu - g[method + "_mu"]).mean() < 3e-6
+    if method == "mcd":                           # nn.Dropout2d is the identity in eval mode (BatchNorm stays in train mode, as everywhere here)
+        for d in net._drops:
+            d.eval()
+        a = net(z).detach(); b = net(z).detach()
+        assert torch.equal(a, b)

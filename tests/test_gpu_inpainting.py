@@ -187,7 +187,8 @@ def test_inpainting_dropin_wrapper_matches_reference_golden(M, golden_dir):
     H = W = 24; seed = 21
     net = skip(8, num_output_channels=4, pad='reflection', num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
                num_channels_skip=[0, 0, 0], filter_size_down=5, filter_size_up=3, filter_skip_size=1, need1x1_up=False,
-               upsample_mode='nearest', need_sigmoid=False)
+               upsample_mode='nearest', dropout_mode_down='None', dropout_mode_up='None', dropout_mode_skip='None', dropout_mode_output='None',
+               need_sigmoid=False)
     net = M.MeanFieldVI(net, prior={'mu': 0.0, 'sigma': 0.1}, replace_layers='all', device=torch.device('cuda'), reparam='', seed=seed)
     assert list(net.state_dict().keys()) == [str(k) for k in g["net_keys"]]
     P, _, _, _ = M.program.skip_program(H, W, input_depth=8, n_out=4, nd=(8, 16, 16), nu=(8, 16, 16), ns=(0, 0, 0), fd=5, fu=3,

@@ -44,7 +44,7 @@ def test_plain_torch_net_agrees_with_oracle():
     mu, rho, bnp = O.init_params(onet, 5)
     conv, bn, n_vi, n_bnp = O.net_table(onet)
     net = M.skip(8, 2, num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16], num_channels_skip=[4, 4, 4],
-                 upsample_mode='bilinear', need_sigmoid=False, pad='reflection')
+                 upsample_mode='bilinear', need_sigmoid=False, pad='reflection', dropout_mode_down='None', dropout_mode_up='None')
     convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
     bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     assert len(convs) == len(conv) and len(bns) == len(bn)
@@ -71,7 +71,15 @@ def test_program_layout_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         M.skip(16, 2, need_sigmoid=False, pad='zero', upsample_mode='bilinear')
     with pytest.raises(NotImplementedError):
+        M.skip(16, 2, need_sigmoid=False, pad='reflection', upsample_mode='bilinear', dropout_mode_down='1d')
+    with pytest.raises(NotImplementedError):
         M.get_net(16, 'UNet', 'reflection', 'bilinear')
+    # the MC-dropout runners' net (bayesian_optimization.py:1526-1549): Dropout2d behind every deeper / up convolution, named like the reference
+    mcd = M.get_net(16, 'skip', 'reflection', 'bilinear', n_channels=2, skip_n33d=[16, 32], skip_n33u=[16, 32], skip_n11=4, num_scales=2,
+                    dropout_mode_down='2d', dropout_p_down=0.3, dropout_mode_up='2d', dropout_p_up=0.3)
+    names = [n for n, m in mcd.named_modules() if isinstance(m, torch.nn.Dropout2d)]
+    assert len(names) == 8 and names[0].endswith("Sequential_deeper_1.Dropout2d_deeper_1") and all(m.p == 0.3 for m in mcd.modules() if isinstance(m, torch.nn.Dropout2d))
+    assert not any(isinstance(m, torch.nn.Dropout2d) for m in M.get_net(16, 'skip', 'reflection', 'bilinear', num_scales=2, skip_n33d=16, skip_n33u=16).modules())
     assert M.sharding.shard_samples(16, 3, 4) == (12, 4)
     with pytest.raises(ValueError):
         M.sharding.shard_samples(10, 0, 4)
