@@ -33,6 +33,7 @@ SIGNATURES = {
     "mfvi_plan_destroy": (None, [_P]),
     "mfvi_plan_workspace_bytes": (_I64, [_P]),
     "mfvi_plan_set_dropout": (_I, [_P, _I]),
+    "mfvi_plan_set_side_stream": (_I, [_P, _I]),
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
     "mfvi_backward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mfvi_plan_read_tensor": (_I, [_P, _P, _I, _I, _I, _P, _P]),

@@ -58,6 +58,10 @@ struct mfvi_plan {
     const void* samp_mu = nullptr; const void* samp_rho = nullptr; const void* samp_ws = nullptr;
     uint64_t samp_seed = 0; uint32_t samp_step = 0, samp_k0 = 0; int samp_n = 0;
     DropEntry* drop_dev = nullptr; int n_drop = 0; bool dropout_on = true;   // Dropout2d layers (MC-dropout sibling)
+    // Backward-weight launches are off the critical path of the backward pass (only grad_finalize needs them): they run on a side
+    // stream of the plan, forked per layer behind the event that marks "dy of this layer is final" and joined before grad_finalize,
+    // so they fill the CUs the latency-bound backward-data / fold kernels of the small maps leave idle.
+    hipStream_t side = nullptr; std::vector<hipEvent_t> fork_events; hipEvent_t join_event = nullptr; bool side_enabled = true;
     GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
     std::vector<GradFinEntry> fin_uploaded;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
@@ -332,10 +336,20 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     if (plan->fin_dev) (void)hipFree(plan->fin_dev);
     if (plan->samp_dev) (void)hipFree(plan->samp_dev);
     if (plan->drop_dev) (void)hipFree(plan->drop_dev);
+    for (auto e : plan->fork_events) (void)hipEventDestroy(e);
+    if (plan->join_event) (void)hipEventDestroy(plan->join_event);
+    if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
 
 int64_t mfvi_plan_workspace_bytes(const mfvi_plan* plan) { return plan ? plan->total_bytes : -1; }
+
+int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled)
+{
+    if (!plan) { set_error("set_side_stream: null plan"); return -1; }
+    plan->side_enabled = enabled != 0;
+    return 0;
+}
 
 int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled)
 {
@@ -414,15 +428,45 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
     }
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
     std::vector<GradFinEntry> fin; int fin_blocks = 0;      // layers whose dW went to partial slabs in this pass
+    // side stream for the backward-weight kernels (MFVI_SIDE_STREAM=0: everything on the caller's stream)
+    static const bool side_on = [] { const char* e = getenv("MFVI_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+    // MFVI_SIDE_MAXPIX: layers with more output pixels per sample keep their backward-weight on the caller's stream (a kernel that
+    // fills the chip by itself gains nothing from sharing it, and its launch duration stays meaningful for the roofline)
+    static const long long side_maxpix = [] { const char* e = getenv("MFVI_SIDE_MAXPIX"); return e ? atoll(e) : (1LL << 40); }();
+    hipStream_t side = st, sw = st; size_t n_fork = 0;
+    if (side_on && plan->side_enabled) {
+        if (!plan->side) {
+            // lowest priority: the caller's stream carries the critical path, the side stream only fills what it leaves idle
+            int prio_least = 0, prio_greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            static const bool low = [] { const char* e2 = getenv("MFVI_SIDE_PRIO"); return !(e2 && e2[0] == '0'); }();
+            hipError_t e = hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, low ? prio_least : 0);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&plan->join_event, hipEventDisableTiming);
+            if (e != hipSuccess) { set_error("backward: side stream setup failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        side = plan->side;
+    }
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) {
         const OpInfo& o = plan->ops[i];
         int rc = 0;
         if (o.d.type == MFVI_OP_CONV) {
             const GView gy = c.gview(o.d.out, dout);
             const TView xin = c.view(o.d.in0);
-            { ProfScope ps(plan, i, PASS_BWD_WEIGHT, st);
+            sw = ((long long)o.g.Ho * o.g.Wo <= side_maxpix) ? side : st;
+            if (sw != st) {      // fork: everything this layer's backward-weight reads (dy, BN-backward sums) is final at this point of `st`
+                if (n_fork == plan->fork_events.size()) {
+                    hipEvent_t ev; const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                    if (e != hipSuccess) { set_error("backward: event creation failed: %s", hipGetErrorString(e)); return (int)e; }
+                    plan->fork_events.push_back(ev);
+                }
+                hipError_t e = hipEventRecord(plan->fork_events[n_fork], st);
+                if (e == hipSuccess) e = hipStreamWaitEvent(sw, plan->fork_events[n_fork], 0);
+                if (e != hipSuccess) { set_error("backward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+                ++n_fork;
+            }
+            { ProfScope ps(plan, i, PASS_BWD_WEIGHT, sw);
               int strips = 0;
-              rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips, n_samples, st) : -2;
+              rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips, n_samples, sw) : -2;
               if (rc == 0) {
                   GradFinEntry e{};
                   e.w_off = o.g.w_off; e.b_off = o.g.b_off; e.part_off = o.part_off; e.stride = o.part_stride;
@@ -431,7 +475,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                   fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS;
                   fin.push_back(e);
               }
-              if (rc == -2 || rc == -3) rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, st); }
+              if (rc == -2 || rc == -3) rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, sw); }
             const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
             if (!rc && need_dx) {
                 const int P = o.g.ks / 2;
@@ -465,7 +509,16 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
             rc = launch_concat_up_bwd(gc, o.d.in0 >= 0 ? &a : nullptr, ga_a, sa, bs_a, c.view(o.d.in1), c.farena() + b.ga_off, b.numel,
                                       b.d.has_bn ? c.bsums() + b.stats_off : nullptr, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
         }
-        if (rc) { if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc)); return rc; }
+        if (rc) {
+            if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc));
+            if (side != st) (void)hipStreamSynchronize(side);   // leave no side-stream work behind a failed call
+            return rc;
+        }
+    }
+    if (side != st) {        // join: grad_finalize (and the caller) see every partial slab / accumulated gradient
+        hipError_t e = hipEventRecord(plan->join_event, side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, plan->join_event, 0);
+        if (e != hipSuccess) { set_error("backward: join failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     if (!fin.empty()) {
         // longest blocks first: a block's work grows with the number of pixel strips of its layer

@@ -150,6 +150,10 @@ class Plan:
         return {i: tuple(dec(lib.mfvi_plan_get_tune(self.handle, i, w)) for w in range(3))
                 for i, o in enumerate(self.prog.ops) if o["type"] == L.OP_CONV}
 
+    def side_stream(self, enabled):
+        """Backward-weight kernels on the plan's side stream (default) or on the caller's stream."""
+        L.check(L.lib().mfvi_plan_set_side_stream(self.handle, int(bool(enabled))))
+
     def profile(self, mode, op=-1, pass_=-1):
         L.check(L.lib().mfvi_plan_profile(self.handle, mode, op, pass_))
 
