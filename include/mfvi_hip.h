@@ -155,6 +155,11 @@ int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_
 /* AdamW with decoupled weight decay (the SGLD sibling: bayesian_optimization.py:1765-1766): p *= 1 - lr*weight_decay first */
 int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, int t, float weight_decay, void* stream);
+/* run_inp_dip's loss (bayesian_optimization.py:2824-2826): F.mse_loss(out[:, :3].sigmoid() * mask, img * mask), mean over 3*H*W;
+ * out[n][4][H][W], target[3][H][W], mask[mask_channels][H][W] (1 or 3).  Same accumulation / gradient contract as
+ * mfvi_gaussian_nll_inpainting (the 4th output channel gets a zero gradient). */
+int mfvi_mse_sigmoid_masked(const float* out, const float* target, const float* mask, int mask_channels, int n, int H, int W,
+                            float grad_scale, float* dout, double* mse_sum, void* stream);
 /* F.mse_loss(out[:, channel], target) of the non-Bayesian siblings (bayesian_optimization.py:1177, 1780; SR :1983-1985 with
  * factor > 1 = the projection out[..., ::f, ::f] first): out[n][C][H][W], target[H/f][W/f]; mse_sum += sum_i mse_i;
  * dout (optional, all C channels written) = grad_scale * d mse_i / d out_i. */

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mfvi_elbo_update_scratch_bytes": (_I64, []),
     "mfvi_elbo_update": (_I, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P, _P, _P]),
     "mfvi_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
+    "mfvi_mse_sigmoid_masked": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_mse_channel": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_uniform_fill_range": (_I, [_U64, _U32, _U32, _U32, _I64, _F, _F, _P, _P]),
     "mfvi_add_normal": (_I, [_P, _U64, _U32, _U32, _I64, _F, _P]),

@@ -75,6 +75,31 @@ __global__ __launch_bounds__(256) void gaussian_nll_inp_kernel(const float* __re
     block_atomic_add(acc * (double)inv_n, nll_sum, s_red);
 }
 
+// ---- run_inp_dip's loss: mse_loss(out[:, :3].sigmoid() * mask, img * mask), mean over 3*H*W ----
+__global__ __launch_bounds__(256) void mse_sigmoid_masked_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                                 const float* __restrict__ mask, int mask_channels, long long HW,
+                                                                 float grad_scale, float* __restrict__ dout, double* __restrict__ mse_sum)
+{
+    __shared__ double s_red[8];
+    const int k = blockIdx.y;
+    const float* __restrict__ o = out + (long long)k * 4 * HW;
+    float* __restrict__ d = dout ? dout + (long long)k * 4 * HW : nullptr;
+    const float inv_n = 1.f / (float)(3 * HW);
+    double acc = 0;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float m = sigmoid_f(o[c * HW + p]);
+            const float mk = mask[(mask_channels == 3 ? c : 0) * HW + p];
+            const float df = m * mk - target[c * HW + p] * mk;
+            acc += (double)(df * df);
+            if (d) d[c * HW + p] = grad_scale * 2.f * df * mk * m * (1.f - m) * inv_n;
+        }
+        if (d) d[3 * HW + p] = 0.f;
+    }
+    block_atomic_add(acc * (double)inv_n, mse_sum, s_red);
+}
+
 // ---- mse_loss on one output channel (DIP / SGLD siblings), optionally after the SR projection out[..., ::f, ::f] ----
 __global__ __launch_bounds__(256) void mse_channel_kernel(const float* __restrict__ out, const float* __restrict__ target, int C, int H, int W,
                                                           int channel, int f, float grad_scale, float* __restrict__ dout, double* __restrict__ mse_sum)
@@ -615,6 +640,17 @@ int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f - lr * weight_decay);
+    return (int)hipGetLastError();
+}
+
+int mfvi_mse_sigmoid_masked(const float* out, const float* target, const float* mask, int mask_channels, int n, int H, int W,
+                            float grad_scale, float* dout, double* mse_sum, void* stream)
+{
+    if (!out || !target || !mask || !mse_sum || n < 1 || H < 1 || W < 1 || (mask_channels != 1 && mask_channels != 3)) {
+        set_error("mse_sigmoid_masked: bad arguments"); return -1; }
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(mse_sigmoid_masked_kernel, dim3(nblocks(HW, 16), n), dim3(256), 0, (hipStream_t)stream, out, target, mask, mask_channels, HW,
+                       grad_scale, dout, mse_sum);
     return (int)hipGetLastError();
 }
 

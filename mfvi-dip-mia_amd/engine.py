@@ -188,8 +188,6 @@ class SiblingEngine(ElboEngine):
                  net_kwargs=None, **kw):
         if method not in (METHOD_DIP, METHOD_MCD, METHOD_SGLD):
             raise ValueError("method %r: 'dip', 'mcd' or 'sgld'" % (method,))
-        if task == TASK_INP and method == METHOD_DIP:
-            raise NotImplementedError("run_inp_dip's masked MSE on the sigmoid output is not built")
         self.method = method
         self.weight_decay, self.gamma, self.param_noise_sigma = float(weight_decay), float(gamma), float(param_noise_sigma)
         nk = dict(net_kwargs or {})
@@ -219,6 +217,9 @@ class SiblingEngine(ElboEngine):
             f = self.sr_factor if self.task == TASK_SR else 1
             L.check(lib.mfvi_mse_channel(L.ptr(self.out), L.ptr(self.target), n, self.out.shape[1], self.H, self.W, 0, f, 1.0 / self.K,
                                          L.ptr(self.dout), L.ptr(self.acc), sp))
+        elif self.task == TASK_INP and self.method == METHOD_DIP:  # mse_loss(out[:, :3].sigmoid() * mask, img * mask)  (:2824-2826)
+            L.check(lib.mfvi_mse_sigmoid_masked(L.ptr(self.out), L.ptr(self.target), L.ptr(self.mask), self.mask.shape[0], n, self.H, self.W,
+                                                1.0 / self.K, L.ptr(self.dout), L.ptr(self.acc), sp))
         else:                                                    # gaussian_nll / radon MSE / masked NLL as in the MFVI runners
             super()._loss_and_dout(n)
 

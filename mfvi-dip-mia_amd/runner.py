@@ -1,5 +1,5 @@
 """Task runners: the reference's run_{den,sr,ct,inp}_mfvi loops (bayesian_optimization.py:1240-1444, 2048-2263, 442-648, 2892-3114)
-and their non-Bayesian siblings run_{den,sr,ct}_{dip,mcd,sgld}, run_inp_{mcd,sgld} (:261-439, 651-1237, 1447-2045, 2266-2692, 3117-3544)
+and their non-Bayesian siblings run_{den,sr,ct,inp}_{dip,mcd,sgld} (:261-439, 651-1237, 1447-2045, 2266-2692, 3117-3544)
 on the fused engine, producing the same artefacts (`save.npz` with the dict-of-'mfvi' object arrays that
 eval_denoising.ipynb / eval_sr.ipynb / eval_ct.ipynb read, `locals.txt`).
 
@@ -216,6 +216,7 @@ def _sibling(task, method, defaults):
         hyper = {k: kw.pop(k, v) for k, v in defaults.items() if k in ("weight_decay", "dropout_p", "gamma")}
         kw.pop("temp", None); kw.pop("sigma", None)
         if task == "inp":
+            hyper.setdefault("weight_decay", 0.0)                     # run_inp_dip: weight_decay = 0 (bayesian_optimization.py:2756)
             return run_inp_mfvi(img=img, imsize=imsize, num_iter=num_iter, lr=lr, input_depth=input_depth, seed=seed, show_every=show_every,
                                 plot=plot, save=save, save_path=save_path, K=K, method=method, **hyper, **kw)
         return _run(task, img, imsize, p_sigma if task == "den" else 0.0, num_iter, lr, 0.0, 0.0, input_depth, seed, show_every, plot, save, save_path, K,
@@ -316,8 +317,9 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
     ssims = mt[:, 4:7]
     if save:
         wrap = lambda a: {method: a}
+        unc = (lambda a: {}) if method == "dip" else wrap            # run_inp_dip leaves UNCERTS_EPI / UNCERTS_ALE empty (:2884-2886)
         np.savez(os.path.join(run_dir, "save.npz"), img_inpainting=img_np, img_mask=mask_np, mse_corrupted=wrap(mse_corrupted), mse_gt=wrap(mse_gt),
-                 recons=wrap(recons), uncerts=wrap(uncerts_epi), uncerts_ale=wrap(uncerts_ale), psnrs=wrap(psnrs), ssims=wrap(ssims))
+                 recons=wrap(recons), uncerts=unc(uncerts_epi), uncerts_ale=unc(uncerts_ale), psnrs=wrap(psnrs), ssims=wrap(ssims))
         with open(os.path.join(run_dir, "locals.txt"), "a") as f:
             print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
         if plot:
@@ -330,6 +332,7 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
                 recons=recons, uncerts=uncerts_epi, uncerts_ale=uncerts_ale, seconds=time.perf_counter() - t0, engine=eng)
 
 
+run_inp_dip = _sibling("inp", "dip", dict(input_depth=32, lr=2e-3))
 run_inp_mcd = _sibling("inp", "mcd", dict(input_depth=32, lr=2e-3, dropout_p=0.2, weight_decay=1e-4))
 run_inp_sgld = _sibling("inp", "sgld", dict(input_depth=32, lr=2e-3, gamma=0.996, weight_decay=1e-4))
 

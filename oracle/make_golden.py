@@ -526,8 +526,28 @@ def golden_siblings():
     np.savez_compressed(os.path.join(GOLD, "siblings.npz"), **res)
 
 
+def golden_inp_dip_loss():
+    """run_inp_dip's data term (bayesian_optimization.py:2822-2826), torch ops as the reference writes them, with a 1- and a 3-channel mask."""
+    import torch.nn.functional as F
+    H, W = 12, 20
+    res = {}
+    for mc in (1, 3):
+        out = torch.from_numpy(O.normal_fill(50 + mc, 2, 1, 0, 0, 4 * H * W).reshape(1, 4, H, W).copy()).requires_grad_(True)
+        img = torch.from_numpy(O.uniform_fill(50 + mc, 2, 0, 0, 3 * H * W).reshape(1, 3, H, W).copy())
+        mask = torch.from_numpy((O.uniform_fill(50 + mc, 3, 0, 0, mc * H * W) > 0.3).astype(np.float32).reshape(1, mc, H, W))
+        out_pred = out[:, :3].sigmoid()
+        loss = F.mse_loss(out_pred * mask, img * mask)
+        loss.backward()
+        res.update({"out%d" % mc: out.detach().numpy()[0], "img%d" % mc: img.numpy()[0], "mask%d" % mc: mask.numpy()[0],
+                    "loss%d" % mc: float(loss), "grad%d" % mc: out.grad.numpy()[0]})
+    np.savez_compressed(os.path.join(GOLD, "inp_dip_loss.npz"), **res)
+    print("inp dip loss", res["loss1"], res["loss3"])
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--inp-dip" in sys.argv:
+        golden_inp_dip_loss(); sys.exit(0)
     if "--siblings" in sys.argv:
         golden_siblings(); sys.exit(0)
     if "--inpainting" in sys.argv:       # only the inpainting fixtures (the others are unchanged)
@@ -544,3 +564,4 @@ if __name__ == "__main__":
     golden_traj("traj_small_k2", small, seed=32, K=2, steps=3)
     golden_inpainting()
     golden_siblings()
+    golden_inp_dip_loss()

@@ -176,6 +176,16 @@ def gaussian_nll_inp(out4, target3, mask, scale=1.0, want_grad=False):
     return (v, d) if want_grad else v
 
 
+def mse_sigmoid_masked(out4, target3, mask, scale=1.0, want_grad=False):
+    """run_inp_dip's loss: F.mse_loss(out4[:3].sigmoid() * mask, target3 * mask); mask (1|3, H, W)."""
+    out4, target3, mask = _f(out4), _f(target3), _f(mask)
+    HW = out4.shape[-1] * out4.shape[-2]
+    d = np.empty_like(out4) if want_grad else None
+    lib().oracle_mse_sigmoid_masked.restype = C.c_double
+    v = lib().oracle_mse_sigmoid_masked(_p(out4), _p(target3), _p(mask), C.c_int(mask.shape[0]), C.c_long(HW), C.c_double(scale), _p(d))
+    return (v, d) if want_grad else v
+
+
 def kl(mu, rho, prior_sigma, prior_mu=0.0, scale=0.0, want_grad=False):
     mu, rho = _f(mu).ravel(), _f(rho).ravel()
     dmu = np.zeros_like(mu) if want_grad else None; drho = np.zeros_like(rho) if want_grad else None

@@ -142,5 +142,8 @@ def test_sibling_runners_other_tasks(M, tmp_path):
                              dropout_p=0.1)
     z = np.load(os.path.join(r["run_dir"], "save.npz"), allow_pickle=True)
     assert z["psnrs"].item()["mcd"].shape == (4, 3) and np.isfinite(z["psnrs"].item()["mcd"]).all()
-    with pytest.raises(NotImplementedError):
-        M.engine.SiblingEngine(64, 64, method="dip", task="inp")
+    r = M.runner.run_inp_dip(img="phantom", imsize=(192, 192), num_iter=40, input_depth=8, seed=1, show_every=20, save=True, save_path=str(tmp_path))
+    z = np.load(os.path.join(r["run_dir"], "save.npz"), allow_pickle=True)
+    ps = z["psnrs"].item()["dip"]
+    assert ps.shape == (41, 3) and np.isfinite(ps).all() and ps[-1, 2] > ps[3, 2] and z["uncerts"].item() == {}
+    assert r["engine"].weight_decay == 0.0

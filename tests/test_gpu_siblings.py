@@ -139,7 +139,8 @@ def test_adamw_mse_channel_sgld_noise(M):
     for f in (1, 4):
         tgt = O.normal_fill(2, 2, 43, 0, 0, (16 // f) * (24 // f)).reshape(16 // f, 24 // f)
         acc = torch.zeros(1, dtype=torch.float64, device="cuda"); dout = torch.full((2, 3, 16, 24), 7.0, device="cuda")
-        L.check(lib.mfvi_mse_channel(L.ptr(dev(out)), L.ptr(dev(tgt)), 2, 3, 16, 24, 1, f, 0.5, L.ptr(dout), L.ptr(acc), sp))
+        d_out, d_tgt = dev(out), dev(tgt)                              # keep the tensors alive across the call
+        L.check(lib.mfvi_mse_channel(L.ptr(d_out), L.ptr(d_tgt), 2, 3, 16, 24, 1, f, 0.5, L.ptr(dout), L.ptr(acc), sp))
         ref = 0.0; dref = np.zeros_like(out)
         for k in range(2):
             v_, d_ = O.mse(out[k, 1, ::f, ::f], tgt, 0.5, want_grad=True)
@@ -187,6 +188,22 @@ def test_fused_elbo_update_equals_kl_plus_adam(M):
     # first-iteration KL of the oracle on the initial parameters
     kl0 = torch.zeros(1, dtype=torch.float64, device="cuda")
     pc = p0.clone(); gc = g0.clone()
-    L.check(lib.mfvi_elbo_update(L.ptr(pc), L.ptr(gc), L.ptr(torch.zeros_like(p0)), L.ptr(torch.zeros_like(p0)), n_vi, n_bn, 0.0, ps, temp, 1e-3,
+    mc, vc = torch.zeros_like(p0), torch.zeros_like(p0)
+    L.check(lib.mfvi_elbo_update(L.ptr(pc), L.ptr(gc), L.ptr(mc), L.ptr(vc), n_vi, n_bn, 0.0, ps, temp, 1e-3,
                                  0.9, 0.999, 1e-8, 1, L.ptr(kl0), L.ptr(scratch), sp))
     assert abs(float(kl0) - ref) < 2e-6 * abs(ref)
+
+
+def test_inp_dip_loss_kernel(M, golden_dir):
+    """mfvi_mse_sigmoid_masked vs the reference's torch expression (tests/golden/inp_dip_loss.npz) and the oracle, n = 2 samples."""
+    lib, L = M._lib.lib(), M._lib
+    g = np.load(os.path.join(golden_dir, "inp_dip_loss.npz"))
+    for mc in (1, 3):
+        o1 = g["out%d" % mc]; H, W = o1.shape[-2:]
+        out = np.stack([o1, o1[::-1].copy()])
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda"); dout = torch.full((2, 4, H, W), 7.0, device="cuda")
+        d_out, d_img, d_mask = dev(out), dev(g["img%d" % mc]), dev(g["mask%d" % mc])      # keep the tensors alive across the call
+        L.check(lib.mfvi_mse_sigmoid_masked(L.ptr(d_out), L.ptr(d_img), L.ptr(d_mask), mc, 2, H, W, 1.0, L.ptr(dout), L.ptr(acc), L.stream_ptr()))
+        v1, d1 = O.mse_sigmoid_masked(out[1], g["img%d" % mc], g["mask%d" % mc], 1.0, want_grad=True)
+        assert abs(float(acc) - (float(g["loss%d" % mc]) + v1)) < 1e-5 * abs(float(acc))
+        assert relerr(host(dout)[0], g["grad%d" % mc]) < 1e-5 and relerr(host(dout)[1], d1) < 1e-5

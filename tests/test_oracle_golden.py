@@ -280,3 +280,12 @@ def test_dropout_mask_spec():
     assert abs((d == 0).mean() - 0.3) < 0.03
     assert not np.array_equal(d, O.dropout_mask(5, 3, 2, 7, 0.3, 4096))      # keyed by the sample
     assert not np.array_equal(d, O.dropout_mask(5, 4, 1, 7, 0.3, 4096))      # ... and the step
+
+
+def test_inp_dip_loss(golden_dir):
+    """run_inp_dip's masked MSE on the sigmoid output (bayesian_optimization.py:2824-2826), 1- and 3-channel masks."""
+    g = load(golden_dir, "inp_dip_loss")
+    for mc in (1, 3):
+        v, d = O.mse_sigmoid_masked(g["out%d" % mc], g["img%d" % mc], g["mask%d" % mc], 1.0, want_grad=True)
+        assert abs(v - float(g["loss%d" % mc])) < 1e-6 * abs(float(g["loss%d" % mc]))
+        assert relerr(d, g["grad%d" % mc]) < 1e-5 and np.all(d[3] == 0)
