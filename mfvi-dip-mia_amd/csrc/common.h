@@ -275,8 +275,12 @@ int launch_conv_bwd_weight(const TView& in, const GView& gy, const ConvGeom& g, 
 // MFMA variants (conv_mfma.hip): return -2 when the shape is not served and the generic kernel must run.
 // w: weights of sample 0, sample k at w + k*wstride (plan.hip: the buffer filled by launch_sample_weights, or mu with stride 0)
 int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
+// fuse (optional, 1x1 layers whose input has no other consumer): the epilogue does the fold of that input tensor itself — multiplies by
+// LeakyReLU'(view(x)), accumulates the BN-backward sums of x (bsums, nullptr when x carries no BatchNorm) and writes ga directly; no
+// padded-gradient scratch, no finalize_dx launch.
+struct FoldFuse { TView x; float* ga = nullptr; long long ga_sstride = 0; double* bsums = nullptr; };
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w, long long wstride, float* dxp, long long dxp_sstride,
-                              int n_samples, hipStream_t st);
+                              int n_samples, hipStream_t st, const FoldFuse* fuse = nullptr);
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
 int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const float* mu, const float* rho, RngKey key,

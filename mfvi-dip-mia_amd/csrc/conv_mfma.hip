@@ -75,6 +75,9 @@ struct MfmaArgs {
     TView xin; GView gin; ConvGeom g;
     const float* w; long long wstride;     // weights of sample k at w + k*wstride (drawn by sample_weights_kernel; stride 0 = mu)
     OutDesc out; float* dxp; long long dxp_sstride;
+    // backward-data of a 1x1 layer whose input has no other consumer: the fold (LeakyReLU', BN-backward sums of the input tensor) runs in
+    // the epilogue and the gradient goes straight to ga (xin = view of that input tensor); fga == nullptr: plain padded-gradient output
+    float* fga; long long fga_sstride; double* fbsums;
     int tiles_x, n_tiles, tiles_per_block;
     int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
     int vec_out;                           // forward: output rows / strides / pointer allow aligned float4 stores
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     // other half of a double buffer.  One barrier per chunk; VALU/VMEM work hides under the matrix pipe.
     extern __shared__ __align__(16) float s_w[];          // WS: [KK][REDP][CTP]; else 2 x [KK][CC][CTP]
     __shared__ __align__(16) float s_x[2][Cfg::X_FLOATS];
-    __shared__ ChanFwd s_ch[MODE == 0 ? MFVI_MAX_C : 1];
+    __shared__ ChanFwd s_ch[(MODE == 0 || KS == 1) ? MFVI_MAX_C : 1];
     __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
     __shared__ double s_red[4][CT][2];
@@ -133,7 +136,10 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         }
     } else {
         for (int c = tid; c < g.Cout; c += 512) s_chb[c] = chan_bwd(A.gin, k, c);
+        if constexpr (KS == 1) { if (A.fga) for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c); }
     }
+    const bool fuse = MODE == 1 && KS == 1 && A.fga != nullptr;
+    const bool fuse_sums = fuse && A.fbsums != nullptr;
 
     // Copy the weight slab of reduction channels [c0, c0+cc) of this sample into wdst[tap][kbase + kk][m] with `nthr` threads.
     //   MODE 0: rows = output channel m, global range ((m0+m)*Cin + c0)*KK + [0, cc*KK),   element -> (kk, tap)
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             }
             lds_barrier();
         }
-        if (MODE == 0 && A.out.stats != nullptr) __syncthreads();        // (Z) consumers publish their BN partial sums
+        if ((MODE == 0 && A.out.stats != nullptr) || fuse_sums) __syncthreads();        // (Z) consumers publish their BN partial sums
     } else {
         // ======================= consumer waves =======================
         int boff[FLAT ? 1 : NF], boffk[FLAT ? NF : 1][FLAT ? KS : 1], frc[FLAT ? NF : 1];
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         const int aoff = l4 * CTP + l15;
         const int wtap = REDP * CTP;
         f32x4 acc[MF][NF];
-        const bool do_stats = MODE == 0 && A.out.stats != nullptr;
+        const bool do_stats = (MODE == 0 && A.out.stats != nullptr) || fuse_sums;
         // BN statistics of this wave's outputs: float partial sums per tile, folded into the wave's fp64 slots in LDS
         if (do_stats && lane < CT) { s_red[wv][lane][0] = 0.0; s_red[wv][lane][1] = 0.0; }
         __syncthreads();                                  // (S0)
@@ -499,7 +505,12 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                     }
                     if (MODE == 1) {
                         const int Hp = g.H + 2 * P, Wp = g.W + 2 * P, HWp = Hp * Wp;
-                        float* __restrict__ o = A.dxp + (long long)k * A.dxp_sstride + (long long)m0 * HWp;
+                        float* __restrict__ o = fuse ? A.fga + (long long)k * A.fga_sstride + (long long)m0 * HWp
+                                                     : A.dxp + (long long)k * A.dxp_sstride + (long long)m0 * HWp;
+                        const float* __restrict__ xraw = fuse_sums ? A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HWp : nullptr;
+                        float fsg[MF][2], fsx[MF][2];
+#pragma unroll
+                        for (int i = 0; i < MF; ++i) { fsg[i][0] = 0.f; fsg[i][1] = 0.f; fsx[i][0] = 0.f; fsx[i][1] = 0.f; }
 #pragma unroll
                         for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -513,6 +524,26 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #pragma unroll
                                 for (int u = 0; u < 2; ++u) {
                                     const int ch = ech + 8 * u, pc = px0 + 4 * ev4;
+                                    if (KS == 1 && fuse) {
+                                        // 1x1, single consumer: no padding ring, (pr, pc) IS the input pixel -> LeakyReLU' and the BN-backward sums here
+                                        if (i * 16 + ch < mt && pr < Hp && pc < Wp) {
+                                            const int ofs = (i * 16 + ch) * HWp + pr * Wp + pc;           // Wp == W, a multiple of 4: aligned float4
+                                            const float4 v = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
+                                            float dd[4] = {v.x, v.y, v.z, v.w};
+                                            if (fuse_sums) {
+                                                const float4 y4 = *reinterpret_cast<const float4*>(xraw + ofs);
+                                                const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+                                                const ChanFwd cf = s_ch[m0 + i * 16 + ch];
+#pragma unroll
+                                                for (int l = 0; l < 4; ++l) {
+                                                    const float vv = __builtin_fmaf(yy[l] - cf.mean, cf.scale, cf.beta);
+                                                    if (A.xin.act && !(vv > 0.f)) dd[l] *= A.xin.slope;
+                                                    fsg[i][u] += dd[l]; fsx[i][u] = __builtin_fmaf(dd[l], (yy[l] - cf.mean) * cf.rstd, fsx[i][u]);
+                                                }
+                                            }
+                                            *reinterpret_cast<float4*>(o + ofs) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                                        }
+                                    } else
                                     if (i * 16 + ch < mt && pr < Hp && pc < Wp) {
                                         float* dst = o + (i * 16 + ch) * HWp + pr * Wp + pc;
                                         const float4 v = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
@@ -522,6 +553,17 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                                 }
                                 __builtin_amdgcn_wave_barrier();
                             }
+                        if (fuse_sums) {        // the 8 lanes that share a channel (ech) -> one partial per channel and wave, into its fp64 slot
+#pragma unroll
+                            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    float a = fsg[i][u], b = fsx[i][u];
+#pragma unroll
+                                    for (int o2 = 4; o2 > 0; o2 >>= 1) { a += __shfl_xor(a, o2, 64); b += __shfl_xor(b, o2, 64); }
+                                    if (ev4 == 0) { s_red[wv][i * 16 + ech + 8 * u][0] += (double)a; s_red[wv][i * 16 + ech + 8 * u][1] += (double)b; }
+                                }
+                        }
                         done = true;
                     }
                 }
@@ -597,7 +639,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             if (t < CT * 2) {
                 const int q = t >> 1, which = t & 1;
                 if (q < mt)
-                    atomicAdd(A.out.stats + ((long long)k * g.Cout + m0 + q) * 2 + which,
+                    atomicAdd((MODE == 0 ? A.out.stats + ((long long)k * g.Cout + m0 + q) * 2 : A.fbsums + ((long long)k * g.Cin + m0 + q) * 2) + which,
                               s_red[0][q][which] + s_red[1][q][which] + s_red[2][q][which] + s_red[3][q][which]);
             }
         }
@@ -613,13 +655,13 @@ int env_tune()
 
 template <int KS, int STRIDE, int MODE>
 int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const float* w, long long wstride, OutDesc out, float* dxp,
-                   long long dxp_sstride, int n_samples, hipStream_t st)
+                   long long dxp_sstride, int n_samples, hipStream_t st, FoldFuse fuse = FoldFuse{})
 {
     const int P = g.ks / 2, KK = KS * KS;
     const int OH = MODE == 0 ? g.Ho : g.H + 2 * P, OW = MODE == 0 ? g.Wo : g.W + 2 * P;    // output pixel domain
     const int MOUT = MODE == 0 ? g.Cout : g.Cin, RED = MODE == 0 ? g.Cin : g.Cout;
     const int RED4 = (RED + 3) & ~3;
-    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1};
+    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, fuse.ga, fuse.ga_sstride, fuse.bsums, 0, 0, 1};
     A.vec_out = MODE == 0 && (g.Wo & 3) == 0 && (out.sstride & 3) == 0 && ((uintptr_t)out.data & 15) == 0;
 
     // Pick the largest tile that still gives the chip enough blocks: big tiles amortise the in-kernel weight sampling
@@ -733,7 +775,7 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
 }
 
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w, long long wstride, float* dxp, long long dxp_sstride,
-                              int n_samples, hipStream_t st)
+                              int n_samples, hipStream_t st, const FoldFuse* fuse)
 {
     if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks == 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
     if ((long long)g.Cin * (g.H + 2) * (g.W + 2) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
@@ -741,6 +783,11 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
     const int wa = g.stride == 2 ? 1 : 3;
     if ((g.Wo & wa) || g.Wo < (wa + 1) || (gy.gstride & wa) || ((uintptr_t)gy.ga & 15) || (gy.y && ((gy.ystride & wa) || ((uintptr_t)gy.y & 15)))) return -2;
     TView none{}; OutDesc od{};
+    if (fuse) {       // 1x1 layer, the fold runs in the epilogue: aligned float4 rows of the input tensor and of its gradient
+        if (g.ks != 1 || !fuse->ga || (g.W & 3) || (fuse->ga_sstride & 3) || ((uintptr_t)fuse->ga & 15)) return -2;
+        if (fuse->bsums && ((fuse->x.sstride & 3) || ((uintptr_t)fuse->x.data & 15))) return -2;
+        return launch_variant<1, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
+    }
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     return -2;

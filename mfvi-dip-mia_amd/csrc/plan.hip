@@ -301,6 +301,13 @@ bool use_mfma()
 // MFVI_GRAD_FROM_SLAB=1: grad_finalize reads eps * softplus(rho) as W_k - mu from the sampled-weight slab instead of re-deriving eps
 // from the counter RNG.  Measured slower on MI355X (87 vs 72 us: the extra 66 MB of loads cost more than the Philox work they save),
 // kept as an A/B switch.
+// MFVI_FOLD_FUSION=0: 1x1 backward-data always goes through the padded-gradient scratch + finalize_dx (A/B and parity cross-checks)
+bool fold_fusion_on()
+{
+    static const bool on = [] { const char* e = getenv("MFVI_FOLD_FUSION"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool grad_from_slab()
 {
     static const bool on = [] { const char* e = getenv("MFVI_GRAD_FROM_SLAB"); return e && e[0] == '1'; }();
@@ -480,11 +487,21 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
             if (!rc && need_dx) {
                 const int P = o.g.ks / 2;
                 const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
-                { ProfScope ps(plan, i, PASS_BWD_DATA, st);
+                const TensorInfo& x = plan->t[o.d.in0];
+                bool folded = false;
+                if (o.g.ks == 1 && x.consumers.size() == 1 && use_mfma() && fold_fusion_on()) {
+                    // 1x1 layer feeding nothing else: backward-data with the fold in its epilogue (no scratch round trip, no finalize_dx launch)
+                    FoldFuse ff; ff.x = xin; ff.ga = (o.d.in0 == plan->input) ? dz : c.farena() + x.ga_off; ff.ga_sstride = x.numel;
+                    ff.bsums = x.d.has_bn ? c.bsums() + x.stats_off : nullptr;
+                    ProfScope ps(plan, i, PASS_BWD_DATA, st);
+                    const int r2 = launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, nullptr, 0, n_samples, st, &ff);
+                    if (r2 == 0) folded = true; else if (r2 != -2 && r2 != -3) rc = r2;
+                }
+                if (!rc && !folded) {
+                  ProfScope ps(plan, i, PASS_BWD_DATA, st);
                   rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, c.farena() + o.scratch_off, per, n_samples, st) : -2;
                   if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
-                const TensorInfo& x = plan->t[o.d.in0];
-                if (!rc && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
+                if (!rc && !folded && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
                     FoldSrc srcs[2]; int ns = 0;
                     for (int ci : x.consumers) {
                         const OpInfo& co = plan->ops[ci]; const int Pc = co.g.ks / 2;
