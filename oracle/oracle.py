@@ -316,7 +316,7 @@ def elbo_grad(net, mu, rho, bn, z, target, task=0, factor=4, theta_deg=None, see
     return dict(loss=loss, nll=nll.value, kl=klv.value, dmu=dmu, drho=drho, dbn=dbn, out=outs)
 
 
-def sibling_grad(net, mu, bn, z, target, loss="mse0", seed=1, step=0, k0=0, K=1, K_total=None, want_out=False):
+def sibling_grad(net, mu, bn, z, target, loss="mse0", seed=1, step=0, k0=0, K=1, K_total=None, want_out=False, factor=1, theta_deg=None):
     """Gradient of the non-Bayesian siblings' loss (DIP / SGLD: F.mse_loss(out[:, :1], y), bayesian_optimization.py:1177,1780;
     MC dropout: gaussian_nll, :1578) averaged over K forwards of the deterministic-weight net (w = mu); Dropout2d masks, when
     the net has them, come from RNG domain 5 keyed by (step, sample)."""
@@ -329,10 +329,17 @@ def sibling_grad(net, mu, bn, z, target, loss="mse0", seed=1, step=0, k0=0, K=1,
     for k in range(k0, k0 + K):
         out, tape = net_forward(net, mu, rho, bn, z, seed, step, k, sample_weights=False)
         dout = np.zeros_like(out)
+        f = factor                                     # SR projection out[..., ::f, ::f] (bayesian_optimization.py:2095-2099)
         if loss == "mse0":
-            v, dout[0] = mse(out[0], target, 1.0 / K_total, want_grad=True)
+            v, g = mse(out[0, ::f, ::f], target, 1.0 / K_total, want_grad=True)
+            dout[0, ::f, ::f] = g
         elif loss == "gnll":
-            v, dout[0], dout[1] = gaussian_nll(out[0], out[1], target, 1.0 / K_total, want_grad=True)
+            v, g0, g1 = gaussian_nll(out[0, ::f, ::f], out[1, ::f, ::f], target, 1.0 / K_total, want_grad=True)
+            dout[0, ::f, ::f] = g0; dout[1, ::f, ::f] = g1
+        elif loss == "radon":                          # mse_loss(radon(out), sinogram) of the CT runs (:377, :789, :991)
+            sino = radon_fwd(out[0], theta_deg)
+            v, ds = mse(sino, target, 1.0 / K_total, want_grad=True)
+            dout[0] = radon_adj(ds, theta_deg, net.H, net.W)
         else:
             raise ValueError(loss)
         total += v / K_total

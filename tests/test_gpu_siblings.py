@@ -207,3 +207,29 @@ def test_inp_dip_loss_kernel(M, golden_dir):
         v1, d1 = O.mse_sigmoid_masked(out[1], g["img%d" % mc], g["mask%d" % mc], 1.0, want_grad=True)
         assert abs(float(acc) - (float(g["loss%d" % mc]) + v1)) < 1e-5 * abs(float(acc))
         assert relerr(host(dout)[0], g["grad%d" % mc]) < 1e-5 and relerr(host(dout)[1], d1) < 1e-5
+
+
+@pytest.mark.parametrize("task,method,loss", [("sr", "dip", "mse0"), ("sr", "mcd", "gnll"), ("sr", "sgld", "gnll"), ("ct", "dip", "radon"),
+                                              ("ct", "mcd", "radon")])
+def test_sibling_losses_on_sr_and_ct(M, task, method, loss):
+    """The siblings' data terms on the other tasks against the oracle: one-channel MSE / Gaussian NLL behind the SR projection
+    (bayesian_optimization.py:1983-1985, 2406, 2614), MSE of the Radon transform (:377, :789, :991)."""
+    from mfvi_dip_mia_amd.engine import SiblingEngine
+    H = W = 32; seed = 9; K = 2
+    small = dict(nd=(8, 16), nu=(8, 16), ns=(4, 4))
+    n_out = 1 if task == "ct" else 2
+    p = 0.25 if method == "mcd" else 0.0
+    eng = SiblingEngine(H, W, method=method, task=task, K=K, input_depth=8, lr=1e-3, seed=seed, dropout_p=p or 0.3, net_kwargs=small, autotune=False)
+    net = O.make_net(H, W, input_depth=8, n_out=n_out, drop_down=p, drop_up=p, **small)
+    img = O.phantom(H, W, seed)
+    theta = np.arange(0, 180., 4., dtype=np.float32)
+    tgt = np.ascontiguousarray(img[::4, ::4]) if task == "sr" else O.radon_fwd(img, theta)
+    eng.set_target(dev(tgt))
+    mu, bnp = host(eng.mu).copy(), host(eng.bn).copy()
+    eng.grad_only(step=2, perturb=True, with_kl=False)
+    z0 = host(eng.z0)
+    z = z0 + 0.1 * O.normal_fill(seed, 1, 0, 0, 2, z0.size).reshape(z0.shape)
+    r = O.sibling_grad(net, mu, bnp, z, tgt, loss=loss, seed=seed, step=2, K=K, want_out=True, factor=4 if task == "sr" else 1, theta_deg=theta)
+    assert relerr(host(eng.out), r["out"]) < 2e-5
+    assert abs(eng.losses()[0] - r["loss"]) < 5e-5 * abs(r["loss"])
+    assert relerr(host(eng.dmu), r["dmu"]) < 3e-4 and relerr(host(eng.dbn), r["dbn"]) < 3e-4
