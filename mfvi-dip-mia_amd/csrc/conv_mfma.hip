@@ -87,9 +87,15 @@ struct MfmaArgs {
 // FLAT: for narrow output domains (<= ~66 wide) a tile is `rt` FULL rows of the domain, its TH*32 pixels dealt to the MFMA
 // fragments in row-major order, instead of a TH x 32 rectangle: a 34-wide padded-gradient domain then fills 99% of the
 // fragments (2 x 32-pixel tile columns fill 53%).  The staged window keeps the same LDS plane with a run-time pitch.
-template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false>
+// PH (MODE 1, stride-2 layers, rectangular tiles): phase decomposition of the transposed convolution.  The gradient wrt the padded input
+// at (r, c) only receives taps with (r + ky) and (c + kx) even; a pixel fragment therefore takes 16 pixels of ONE column parity
+// (columns px0 + 2*l15 + parity) of one row, and issues the 1 / 2 / 2 / 4 of the 9 taps its (row parity, column parity) class can see,
+// reading the UN-stuffed dy window ((TH/2 + 2) rows x 24 columns) — a quarter of the MFMAs and of the staged window of the
+// zero-stuffed formulation, same per-element accumulation order (the skipped products are exact zeros).
+template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false, bool PH = false>
 __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
 {
+    static_assert(!PH || (MODE == 1 && KS == 3 && !FLAT && !BIGC), "phase decomposition: 3x3 backward-data on rectangular tiles");
     using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
@@ -265,15 +271,15 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         // Item q = lane + 64*j of a channel is float4 column v of window row iy (NV4 columns per row).  A float4 is wholly
         // inside or wholly outside the image (tile origins and image widths are multiples of 4); reflection only ever needs
         // one element of an outside float4 (column -1 <- x[1], column W <- x[W-2]), taken from the neighbouring inside one.
-        constexpr int NV4 = PITCH / 4, NITEM = IN_TH * NV4, NV = (NITEM + 63) / 64;
+        constexpr int NV4 = PH ? 6 : PITCH / 4, NITEM = (PH ? TH / 2 + 2 : IN_TH) * NV4, NV = (NITEM + 63) / 64;
         int voff[FLAT ? 1 : NV];          // global element offset of the float4 to load (always valid), with flags in the low 2 bits:
                                           // 1 = left-reflected (keep .y as column 3), 2 = right-reflected (.z as column 0), 3 = stage zeros
         float4 xv[FLAT ? 1 : CPW][FLAT ? 1 : NV], yv[(!FLAT && MODE == 1) ? CPW : 1][(!FLAT && MODE == 1) ? NV : 1];
         auto set_tile_v = [&](int tile) {
             const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
-            const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
-            const int ax0 = (MODE == 0 ? px0 * STRIDE : px0) - Cfg::HALO4;            // aligned first column of the LDS row
-            const bool stuffed = MODE == 1 && g.stride == 2;
+            const int sy0 = PH ? py0 / 2 - 1 : (MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1));
+            const int ax0 = (PH ? px0 / 2 : (MODE == 0 ? px0 * STRIDE : px0)) - Cfg::HALO4;            // aligned first column of the LDS row
+            const bool stuffed = !PH && MODE == 1 && g.stride == 2;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int q = min(lane + 64 * j, NITEM - 1), iy = q / NV4, v = q - iy * NV4;
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             }
         };
         auto prefetch_v = [&](int c0) {
-            const bool stuffed = MODE == 1 && g.stride == 2;
+            const bool stuffed = !PH && MODE == 1 && g.stride == 2;
 #pragma unroll
             for (int i = 0; i < CPW; ++i) {
                 const long long cb = (long long)min(c0 + pw * CPW + i, RED - 1) * SHW;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         };
         auto store_v = [&](int c0, float* __restrict__ dst) {    // registers -> LDS with the deferred transform
             const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
-            const bool stuffed = MODE == 1 && g.stride == 2;
+            const bool stuffed = !PH && MODE == 1 && g.stride == 2;
 #pragma unroll
             for (int i = 0; i < CPW; ++i) {
                 const int cl = pw * CPW + i;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                 for (int ky = 0; ky < KS; ++ky) boffk[f][ky] = base + ky * A.wpitch;
             } else {
                 const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
-                boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? (MODE == 0 ? 3 : 2) : 0);
+                if constexpr (PH) boff[f] = l4 * PLANE + (wv * (TH / 8)) * 24 + l15 + 3;      // window row (R + r + ky)/2, R = wv*TH/4 even; column l15 + (parity + kx)/2 + 3
+                else boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? (MODE == 0 ? 3 : 2) : 0);
             }
         }
         const int aoff = l4 * CTP + l15;
@@ -419,18 +426,26 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #pragma unroll
                     for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + (sbase + st_) * 4 * CTP + i * 16];
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) bb[f] = FLAT ? sx[(sbase + st_) * 4 * PLANE + boffk[f][ky] + kx] : sx[(sbase + st_) * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                    for (int f = 0; f < NF; ++f) {
+                        if constexpr (PH) {        // fragment f: row parity (f >> 1) & 1, column parity f & 1
+                            if ((((f >> 1) + ky) & 1) == 0 && (((f & 1) + kx) & 1) == 0)
+                                bb[f] = sx[(sbase + st_) * 4 * PLANE + boff[f] + (((f >> 1) + ky) >> 1) * 24 + (((f & 1) + kx) >> 1)];
+                        } else
+                        bb[f] = FLAT ? sx[(sbase + st_) * 4 * PLANE + boffk[f][ky] + kx] : sx[(sbase + st_) * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                    }
                 };
 #pragma unroll
                 for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if (q + SG - 1 < NQ) load(q + SG - 1, a[(q + SG - 1) % SG], b[(q + SG - 1) % SG]);
+                    const int tapq = q / STEPS, kyq = tapq / KS, kxq = tapq % KS;
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
                         for (int f = 0; f < NF; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q % SG][i], b[q % SG][f], acc[i][f], 0, 0, 0);
+                            if (!PH || ((((f >> 1) + kyq) & 1) == 0 && (((f & 1) + kxq) & 1) == 0))
+                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q % SG][i], b[q % SG][f], acc[i][f], 0, 0, 0);
                 }
             };
             if constexpr (CC == 8) {
@@ -519,7 +534,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #pragma unroll
                                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) ep[l4 * 4 + r][h * 16 + l15] = acc[i][2 * rp + h][r];
+                                    for (int r = 0; r < 4; ++r) ep[l4 * 4 + r][PH ? 2 * l15 + h : h * 16 + l15] = acc[i][2 * rp + h][r];
                                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                                 for (int u = 0; u < 2; ++u) {
@@ -646,6 +661,13 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     }
 }
 
+// MFVI_PHASE=0: stride-2 backward-data on rectangular tiles runs the zero-stuffed formulation (A/B and parity cross-checks)
+bool phase_on()
+{
+    static const bool on = [] { const char* e = getenv("MFVI_PHASE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // Tiling override: MFVI_TUNE=mf,th,T (experiments) or the per-op choice made by mfvi_plan_autotune (ConvGeom::tune).
 int env_tune()
 {
@@ -692,6 +714,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         }                                                                                                                  \
         const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
         constexpr bool CAN_BIG = (KS == 1 && !(FL_)) || (KS == 3 && STRIDE == 1 && MODE == 0 && (FL_) && TH_ <= 4);   /* backward-data stages two tensors: measured slower with big stages */ \
+        constexpr bool CAN_PH = MODE == 1 && KS == 3 && !(FL_);                                                           \
+        const bool ph = CAN_PH && g.stride == 2 && phase_on() && (g.Wo & 3) == 0 && (gin.gstride & 3) == 0 && (!gin.y || (gin.ystride & 3) == 0); \
         using BigCfg = MCfg<KS, STRIDE, MF_, TH_, CAN_BIG>;                                                                \
         bool big = CAN_BIG && RED >= 64;                                                                                   \
         const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP;                                              \
@@ -706,6 +730,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
             if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
         } else {                                                                                                           \
             if (forced_T > 1) return -3;                                                                                   \
@@ -714,6 +739,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
             if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
