@@ -385,6 +385,41 @@ def test_tilings_do_not_change_results(M, shape):
                 assert relerr(a, b) < 2e-5, (name, which, cand)
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 64, 64), (64, 128, 32, 32)])
+def test_stride2_tilings_do_not_change_results(M, shape):
+    """Stride-2 layers: the phase-decomposed backward-data on rectangular tiles (every fragment count / tile height / tiles per block),
+    the zero-stuffed formulation on FLAT tiles, and the oracle all agree; the forward tilings too."""
+    cin, cout, H, W = shape
+    n, seed = 2, 78
+    P = M.Program()
+    zin = P.tensor(cin, H, W)
+    x = P.tensor(cin, H, W); P.conv(zin, x, 1, 1); P.set_bn(x, act=True)
+    y = P.tensor(cout, H // 2, W // 2); P.conv(x, y, 3, 2); P.set_bn(y, act=True)
+    out = P.tensor(2, H // 2, W // 2); P.conv(y, out, 1, 1)
+    plan = P.compile(zin, out, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * (H // 2) * (W // 2)).reshape(n, 2, H // 2, W // 2))
+    lib = M._lib.lib()
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    enc = lambda a, b, c: a | b << 8 | c << 16
+    tried = 0
+    for which, cands in ((0, [(1, 8, 1), (2, 8, 1), (1, 8, 2), (1, 8 | 128, 1), (2, 4 | 128, 1)]),
+                         (1, [(1, 8, 1), (2, 8, 1), (3, 8, 1), (1, 16, 1), (2, 16, 1), (1, 8, 2), (1, 8 | 128, 1), (2, 8 | 128, 1), (1, 16 | 128, 1), (2, 4 | 128, 1)])):
+        for cand in cands:
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc(*cand)))
+            try:
+                got = _run_plan(plan, P, seed, n, z, dout)
+            except M._lib.MfviError:          # a tiling this shape does not admit (-3): the launcher refuses it, nothing ran
+                continue
+            finally:
+                M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, 0))
+            tried += 1
+            assert relerr(got[0], ref[0]) < 1e-6, ("out", which, cand)
+            for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+                assert relerr(a, b) < 2e-5, (name, which, cand)
+    assert tried >= 8
+
+
 def test_autotune_cache_and_reproducible_gradients(M, tmp_path):
     cin, cout, H, W, n, seed = 36, 16, 32, 32, 4, 5
     P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
