@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MFVI_ABI_VERSION 2
+#define MFVI_ABI_VERSION 3
 
 typedef struct mfvi_plan mfvi_plan;
 
@@ -129,6 +129,15 @@ int mfvi_gaussian_nll(const float* out, const float* target, int n, int H, int W
  * mfvi_gaussian_nll. */
 int mfvi_gaussian_nll_inpainting(const float* out, const float* target, const float* mask, int mask_channels, int n, int H, int W,
                                  float grad_scale, float* dout, double* nll_sum, void* stream);
+/* The same two losses in the call shape of the reference's functions — separate tensors, as the drop-in `gaussian_nll(out[:, :1],
+ * out[:, 1:], target)` / `gaussian_nll_inpainting(out_pred, out[:, 3:], img, mask)` hand them over (utils/bayesian_utils.py:29-39):
+ * mu / target [C][HW], neg_logvar [Cs][HW] with Cs == C or 1 (broadcast over channels), mask NULL or [Cm][HW] with Cm == C or 1.
+ * loss_out (device double, overwritten) = mean (reduction_mean) or sum of (exp(s) (target - mu)^2 - s) * mask, s = clamp(neg_logvar, -20, 20).
+ * The backward multiplies by the upstream gradient read from DEVICE memory (grad_out[0]): no host sync inside autograd. */
+int mfvi_gaussian_nll_tensors(const float* mu, const float* neg_logvar, const float* target, const float* mask, int C, int Cs, int Cm, int64_t HW,
+                              int reduction_mean, double* loss_out, void* stream);
+int mfvi_gaussian_nll_tensors_backward(const float* mu, const float* neg_logvar, const float* target, const float* mask, int C, int Cs, int Cm,
+                                       int64_t HW, int reduction_mean, const float* grad_out, float* dmu, float* dneg_logvar, void* stream);
 int mfvi_radon_mse(const float* out, const float* sino, const float* theta_deg, int n, int H, int W, int T,
                    float grad_scale, float* scratch, float* dout, double* mse_sum, void* stream);
 int mfvi_radon_forward(const float* img, const float* theta_deg, int n, int H, int W, int T, float* sino, void* stream);
@@ -152,6 +161,19 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int64_t mfvi_elbo_update_scratch_bytes(void);
 int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma,
                      float temp, float lr, float beta1, float beta2, float eps, int t, double* kl_out, void* scratch, void* stream);
+/* The CT runners' NaN guard, `if not torch.isnan(loss): optimizer.step()` (bayesian_optimization.py:380, 581-582, 792, 994), without a host
+ * sync.  loss = data term + temp * KL, and KL is a function of the parameters alone (finite while every earlier update was), so the guard
+ * reads the DATA-TERM scalar of this iteration on the device: loss_d (the double accumulator of mfvi_radon_mse & co) and / or loss_f (the
+ * float that rode the K-sharded all-reduce); either may be NULL.  NaN there: params / m / v are left untouched (kl_out is still written)
+ * and *t_applied — the device counter of APPLIED updates that sets Adam's bias corrections, like torch's per-parameter state['step'] —
+ * is not advanced.  Otherwise the update is number *t_applied + 1 and mfvi_elbo_update_guarded advances the counter itself;
+ * mfvi_adamw_step_guarded only reads it (one optimizer step may cover several parameter blocks): call mfvi_step_advance once after them. */
+int mfvi_elbo_update_guarded(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma,
+                             float temp, float lr, float beta1, float beta2, float eps, int32_t* t_applied, const double* loss_d,
+                             const float* loss_f, double* kl_out, void* scratch, void* stream);
+int mfvi_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            const int32_t* t_applied, const double* loss_d, const float* loss_f, float weight_decay, void* stream);
+int mfvi_step_advance(int32_t* t_applied, const double* loss_d, const float* loss_f, void* stream);
 /* AdamW with decoupled weight decay (the SGLD sibling: bayesian_optimization.py:1765-1766): p *= 1 - lr*weight_decay first */
 int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, int t, float weight_decay, void* stream);
@@ -186,6 +208,9 @@ int mfvi_sq_err_sum(const float* a, const float* b, int64_t n, double* sum_out, 
 /* SSIM map mean (11x11 Gaussian sigma 1.5, zero padding) of two [H][W] images; ssim_sum overwritten with the
  * sum of the SSIM map (divide by H*W). */
 int mfvi_ssim_sum(const float* a, const float* b, int H, int W, double* ssim_sum, void* stream);
+/* dst[h][w] = src[y*factor][x*factor]: the SR runner's nearest-neighbour downsampler (bayesian_optimization.py:2095-2099) applied to the
+ * smoothed / clipped outputs for the low-resolution metrics (:2203, :2207, :2214-2217); h = H / factor, w = W / factor. */
+int mfvi_decimate(const float* src, int H, int W, int factor, float* dst, void* stream);
 /* One pass of the runner's per-iteration bookkeeping (bayesian_optimization.py:1374-1396) with no host sync: sample means of
  * out[:,0] and exp(-out[:,1]), EMA (weight w; first = 1 copies), clipped copies for the metrics, ring-buffer slot writes
  * (slot pointers may be NULL).  C = 2 (den/SR) or 1 (CT: no aleatoric channel). */

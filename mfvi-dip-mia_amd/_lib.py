@@ -44,6 +44,8 @@ SIGNATURES = {
     "mfvi_plan_set_tune": (_I, [_P, _I, _I, _I]),
     "mfvi_gaussian_nll": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_gaussian_nll_inpainting": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "mfvi_gaussian_nll_tensors": (_I, [_P, _P, _P, _P, _I, _I, _I, _I64, _I, _P, _P]),
+    "mfvi_gaussian_nll_tensors_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I64, _I, _P, _P, _P, _P]),
     "mfvi_radon_mse": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "mfvi_radon_forward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "mfvi_radon_adjoint": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
@@ -52,6 +54,10 @@ SIGNATURES = {
     "mfvi_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _P]),
     "mfvi_elbo_update_scratch_bytes": (_I64, []),
     "mfvi_elbo_update": (_I, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P, _P, _P]),
+    "mfvi_elbo_update_guarded": (_I, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "mfvi_adamw_step_guarded": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _P, _P, _F, _P]),
+    "mfvi_step_advance": (_I, [_P, _P, _P, _P]),
+    "mfvi_decimate": (_I, [_P, _I, _I, _I, _P, _P]),
     "mfvi_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "mfvi_mse_sigmoid_masked": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_mse_channel": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),

@@ -546,8 +546,52 @@ class FusedNet(MeanFieldVI):
         return grads, dz
 
 
+class _GaussianNLL(torch.autograd.Function):
+    """Forward and backward of the two NLLs on the HIP kernels (mfvi_gaussian_nll_tensors[_backward]); the upstream gradient stays on
+    the device."""
+
+    @staticmethod
+    def forward(ctx, mu, neg_logvar, target, mask, mean):
+        mu_c, s_c = mu.contiguous().float(), neg_logvar.contiguous().float()
+        C, hw = (mu_c.shape[1], mu_c[0, 0].numel()) if mu_c.dim() >= 3 else (1, mu_c.numel())
+        if mu_c.dim() >= 3 and mu_c.shape[0] != 1:
+            raise NotImplementedError("batch size %d: the deep-image-prior losses act on one image" % mu_c.shape[0])
+        t_c = target.expand_as(mu_c).contiguous().float()
+        Cs = s_c.numel() // hw
+        if s_c.numel() != Cs * hw or Cs not in (1, C):
+            raise NotImplementedError("neg_logvar of shape %s does not broadcast over mu of shape %s along the channel axis" % (tuple(s_c.shape), tuple(mu_c.shape)))
+        m_c, Cm = None, 1
+        if mask is not None:
+            m_c = mask.contiguous().float(); Cm = m_c.numel() // hw
+            if m_c.numel() != Cm * hw or Cm not in (1, C):
+                raise NotImplementedError("mask of shape %s does not broadcast over mu of shape %s along the channel axis" % (tuple(m_c.shape), tuple(mu_c.shape)))
+        acc = torch.empty(1, dtype=torch.float64, device=mu_c.device)
+        L.check(L.lib().mfvi_gaussian_nll_tensors(L.ptr(mu_c), L.ptr(s_c), L.ptr(t_c), L.ptr(m_c), C, Cs, Cm, hw, int(mean), L.ptr(acc), L.stream_ptr()))
+        ctx.save_for_backward(mu_c, s_c, t_c, m_c)
+        ctx.dims = (C, Cs, Cm, hw, int(mean), mu.shape, neg_logvar.shape)
+        return acc.float()[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        mu_c, s_c, t_c, m_c = ctx.saved_tensors
+        C, Cs, Cm, hw, mean, mu_shape, s_shape = ctx.dims
+        dmu, ds = torch.empty_like(mu_c), torch.empty_like(s_c)
+        L.check(L.lib().mfvi_gaussian_nll_tensors_backward(L.ptr(mu_c), L.ptr(s_c), L.ptr(t_c), L.ptr(m_c), C, Cs, Cm, hw, mean,
+                                                           L.ptr(g.reshape(1).contiguous().float()), L.ptr(dmu), L.ptr(ds), L.stream_ptr()))
+        return dmu.view(mu_shape), ds.view(s_shape), None, None, None
+
+
+def _reduction(reduction):
+    if reduction not in ('mean', 'sum'):
+        raise ValueError("reduction=%r: 'mean' or 'sum'" % (reduction,))
+    return reduction == 'mean'
+
+
 def gaussian_nll(mu, neg_logvar, target, reduction='mean'):
-    """utils/bayesian_utils.py:29-32, kept as plain torch for code that calls it on the wrapper's output."""
-    neg_logvar = torch.clamp(neg_logvar, min=-20, max=20)
-    loss = torch.exp(neg_logvar) * torch.pow(target - mu, 2) - neg_logvar
-    return loss.mean() if reduction == 'mean' else loss.sum()
+    """Drop-in for utils/bayesian_utils.py:29-32 on the HIP kernels: same arguments, a 0-dim differentiable tensor back."""
+    return _GaussianNLL.apply(mu, neg_logvar, target, None, _reduction(reduction))
+
+
+def gaussian_nll_inpainting(mu, neg_logvar, target, mask, reduction='mean'):
+    """Drop-in for utils/bayesian_utils.py:35-39 (masked; neg_logvar broadcasts over the colour channels) on the HIP kernels."""
+    return _GaussianNLL.apply(mu, neg_logvar, target, mask, _reduction(reduction))

@@ -75,6 +75,45 @@ __global__ __launch_bounds__(256) void gaussian_nll_inp_kernel(const float* __re
     block_atomic_add(acc * (double)inv_n, nll_sum, s_red);
 }
 
+
+// ---- gaussian_nll / gaussian_nll_inpainting on separate mu / neg_logvar tensors (the call shape of the drop-in API) ----
+// loss[c][p] = (exp(s) * (t[c][p] - mu[c][p])^2 - s) * mask,  s = clamp(s_raw[Cs == 1 ? 0 : c][p], -20, 20)
+__global__ __launch_bounds__(256) void gnll_bcast_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sraw, const float* __restrict__ target,
+                                                             const float* __restrict__ mask, int C, int Cs, int Cm, long long HW, double scale,
+                                                             double* __restrict__ loss_sum)
+{
+    __shared__ double s_red[8];
+    double acc = 0;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256)
+        for (int c = 0; c < C; ++c) {
+            const float s = fminf(fmaxf(sraw[(Cs == 1 ? 0 : c) * HW + p], -20.f), 20.f);
+            const float df = target[c * HW + p] - mu[c * HW + p];
+            const float mk = mask ? mask[(Cm == 1 ? 0 : c) * HW + p] : 1.f;
+            acc += (double)((expf(s) * df * df - s) * mk);
+        }
+    block_atomic_add(acc * scale, loss_sum, s_red);
+}
+__global__ __launch_bounds__(256) void gnll_bcast_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sraw, const float* __restrict__ target,
+                                                             const float* __restrict__ mask, int C, int Cs, int Cm, long long HW, float scale,
+                                                             const float* __restrict__ gout, float* __restrict__ dmu, float* __restrict__ ds)
+{
+    const float g = gout[0] * scale;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+        float dsum = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float sr = sraw[(Cs == 1 ? 0 : c) * HW + p];
+            const float s = fminf(fmaxf(sr, -20.f), 20.f);
+            const bool inside = (sr >= -20.f) && (sr <= 20.f);
+            const float df = target[c * HW + p] - mu[c * HW + p], e = expf(s);
+            const float mk = mask ? mask[(Cm == 1 ? 0 : c) * HW + p] : 1.f;
+            dmu[c * HW + p] = g * (-2.f * e * df) * mk;
+            const float d = inside ? g * (e * df * df - 1.f) * mk : 0.f;
+            if (Cs == 1) dsum += d; else ds[c * HW + p] = d;
+        }
+        if (Cs == 1) ds[p] = dsum;
+    }
+}
+
 // ---- run_inp_dip's loss: mse_loss(out[:, :3].sigmoid() * mask, img * mask), mean over 3*H*W ----
 __global__ __launch_bounds__(256) void mse_sigmoid_masked_kernel(const float* __restrict__ out, const float* __restrict__ target,
                                                                  const float* __restrict__ mask, int mask_channels, long long HW,
@@ -168,11 +207,36 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ m
     }
 }
 
-// ---- AdamW(wd = 0) ------------------------------------------------------------------------------
+// ---- AdamW -----------------------------------------------------------------------------------------
+// NaN guard of the CT runners (bayesian_optimization.py:380, 581-582, 792, 994: `if not torch.isnan(loss): optimizer.step()`) without a
+// host sync: the data-term scalar of this iteration is read on the device (double accumulator and / or the float that rode the
+// all-reduce); a NaN there leaves p, m, v untouched and the step counter of APPLIED updates (which sets the bias corrections, like
+// torch's per-parameter state['step']) is not advanced.
+struct StepGuard { const int* t_applied; const double* loss_d; const float* loss_f; };
+__device__ __forceinline__ bool guard_skip(const StepGuard& g)
+{
+    return (g.loss_d && isnan(*g.loss_d)) || (g.loss_f && isnan(*g.loss_f));
+}
+// bias corrections of update number t (1-based): step_size = lr / (1 - b1^t), inv_sqrt_bc2 = 1 / sqrt(1 - b2^t); one lane per block
+__device__ __forceinline__ void adam_bias(const StepGuard& g, float lr, float b1, float b2, float* s_bc, float& step_size, float& inv_sqrt_bc2)
+{
+    if (g.t_applied == nullptr) return;              // host-computed values stay
+    if (threadIdx.x == 0) {
+        const int t = *g.t_applied + 1;
+        s_bc[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+        s_bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)t)));
+    }
+    __syncthreads();
+    step_size = s_bc[0]; inv_sqrt_bc2 = s_bc[1];
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float b1, float b2, float eps,
-                                                   float step_size, float inv_sqrt_bc2, float decay)
+                                                   float step_size, float inv_sqrt_bc2, float decay, float lr, StepGuard guard)
 {
+    __shared__ float s_bc[2];
+    if (guard_skip(guard)) return;
+    adam_bias(guard, lr, b1, b2, s_bc, step_size, inv_sqrt_bc2);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -180,6 +244,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mi; v[i] = vi;
         p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));       // decay = 1 - lr*wd (exactly 1 for wd = 0)
     }
+}
+__global__ void step_advance_kernel(int* __restrict__ t_applied, StepGuard guard)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !guard_skip(guard)) *t_applied += 1;
 }
 
 // ---- fused tail of an ELBO iteration: KL, its gradient and AdamW(wd = 0) over [MU | RHO | BN] in one pass ----
@@ -191,9 +259,13 @@ struct ElboUpdateScratch { double partial[ELBO_UPDATE_MAX_BLOCKS]; };
 
 __global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                           long long n_vi, long long n_bn, float m0, float s0, float temp, float b1, float b2,
-                                                          float eps, float step_size, float inv_sqrt_bc2, ElboUpdateScratch* __restrict__ sc)
+                                                          float eps, float step_size, float inv_sqrt_bc2, ElboUpdateScratch* __restrict__ sc, float lr,
+                                                          StepGuard guard)
 {
     __shared__ double s_red[8];
+    __shared__ float s_bc[2];
+    const bool skip = guard_skip(guard);             // NaN data term: KL is still reported, nothing is written
+    adam_bias(guard, lr, b1, b2, s_bc, step_size, inv_sqrt_bc2);
     const float log_s0 = logf(s0), s0sq = s0 * s0;
     auto adam = [&](long long i, float gi) {
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -206,22 +278,35 @@ __global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p,
         const float mu = p[i], r = p[n_vi + i];
         const float s = softplus_f(r), d = mu - m0, inv = 1.f / s;
         acc += (double)(logf(s) - log_s0) + (double)((s0sq + d * d) / (2.f * s * s)) - 0.5;
+        if (skip) continue;
         const float gmu = g[i] + temp * d * inv * inv;
         const float grho = g[n_vi + i] + temp * (inv - (s0sq + d * d) * inv * inv * inv) * sigmoid_f(r);
         g[i] = gmu; g[n_vi + i] = grho;
         adam(i, gmu); adam(n_vi + i, grho);
     }
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) adam(2 * n_vi + i, g[2 * n_vi + i]);
+    if (!skip)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) adam(2 * n_vi + i, g[2 * n_vi + i]);
     const double tot = block_sum_d(acc, s_red);
     if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(256) void elbo_update_finish_kernel(const ElboUpdateScratch* __restrict__ sc, int n_blocks, double* __restrict__ kl_out)
+__global__ __launch_bounds__(256) void elbo_update_finish_kernel(const ElboUpdateScratch* __restrict__ sc, int n_blocks, double* __restrict__ kl_out,
+                                                                 int* __restrict__ t_applied, StepGuard guard)
 {
     __shared__ double s_red[8];
     double t = 0;
     for (int b = threadIdx.x; b < n_blocks; b += 256) t += sc->partial[b];
     t = block_sum_d(t, s_red);
-    if (threadIdx.x == 0) *kl_out = t;
+    if (threadIdx.x == 0) { *kl_out = t; if (t_applied && !guard_skip(guard)) *t_applied += 1; }
+}
+
+// nearest /f projection x[..., ::f, ::f] (the SR runner's downsampler: bayesian_optimization.py:2095-2099)
+__global__ __launch_bounds__(256) void decimate_kernel(const float* __restrict__ src, int W, int f, int h, int w, float* __restrict__ dst)
+{
+    const long long n = (long long)h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        dst[i] = src[(long long)(y * f) * W + (long long)x * f];
+    }
 }
 
 // ---- RNG fills ------------------------------------------------------------------------------------
@@ -586,6 +671,29 @@ int mfvi_gaussian_nll_inpainting(const float* out, const float* target, const fl
     return (int)hipGetLastError();
 }
 
+
+int mfvi_gaussian_nll_tensors(const float* mu, const float* neg_logvar, const float* target, const float* mask, int C, int Cs, int Cm, int64_t HW,
+                              int reduction_mean, double* loss_out, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!mu || !neg_logvar || !target || !loss_out || C < 1 || HW < 1 || (Cs != 1 && Cs != C) || (mask && Cm != 1 && Cm != C)) {
+        set_error("gaussian_nll_tensors: bad arguments (C=%d Cs=%d Cm=%d HW=%lld)", C, Cs, Cm, (long long)HW); return -1; }
+    hipError_t e = hipMemsetAsync(loss_out, 0, sizeof(double), st); if (e) return (int)e;
+    hipLaunchKernelGGL(gnll_bcast_fwd_kernel, dim3(nblocks(HW, 16)), dim3(256), 0, st, mu, neg_logvar, target, mask, C, Cs, Cm, (long long)HW,
+                       reduction_mean ? 1.0 / ((double)C * (double)HW) : 1.0, loss_out);
+    return (int)hipGetLastError();
+}
+
+int mfvi_gaussian_nll_tensors_backward(const float* mu, const float* neg_logvar, const float* target, const float* mask, int C, int Cs, int Cm,
+                                       int64_t HW, int reduction_mean, const float* grad_out, float* dmu, float* dneg_logvar, void* stream)
+{
+    if (!mu || !neg_logvar || !target || !grad_out || !dmu || !dneg_logvar || C < 1 || HW < 1 || (Cs != 1 && Cs != C) || (mask && Cm != 1 && Cm != C)) {
+        set_error("gaussian_nll_tensors_backward: bad arguments"); return -1; }
+    hipLaunchKernelGGL(gnll_bcast_bwd_kernel, dim3(nblocks(HW)), dim3(256), 0, (hipStream_t)stream, mu, neg_logvar, target, mask, C, Cs, Cm, (long long)HW,
+                       reduction_mean ? (float)(1.0 / ((double)C * (double)HW)) : 1.f, grad_out, dmu, dneg_logvar);
+    return (int)hipGetLastError();
+}
+
 int mfvi_kl(const float* mu, const float* rho, int64_t n, float prior_mu, float prior_sigma, double* kl_out, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -612,7 +720,7 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f, lr, StepGuard{nullptr, nullptr, nullptr});
     return (int)hipGetLastError();
 }
 
@@ -627,8 +735,50 @@ int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_
     const long long work = n_vi > n_bn ? n_vi : n_bn;
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
-                       prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (ElboUpdateScratch*)scratch);
-    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out);
+                       prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (ElboUpdateScratch*)scratch, lr,
+                       StepGuard{nullptr, nullptr, nullptr});
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, (int*)nullptr,
+                       StepGuard{nullptr, nullptr, nullptr});
+    return (int)hipGetLastError();
+}
+
+int mfvi_elbo_update_guarded(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma, float temp,
+                             float lr, float beta1, float beta2, float eps, int32_t* t_applied, const double* loss_d, const float* loss_f,
+                             double* kl_out, void* scratch, void* stream)
+{
+    if (!params || !grads || !m || !v || !kl_out || !scratch || !t_applied || n_vi < 0 || n_bn < 0 || !(prior_sigma > 0.f)) {
+        set_error("elbo_update_guarded: bad arguments (t_applied: device counter of applied updates)"); return -1; }
+    const long long work = n_vi > n_bn ? n_vi : n_bn;
+    const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
+    const StepGuard guard{t_applied, loss_d, loss_f};
+    hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
+                       prior_mu, prior_sigma, temp, beta1, beta2, eps, 0.f, 0.f, (ElboUpdateScratch*)scratch, lr, guard);
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, t_applied, guard);
+    return (int)hipGetLastError();
+}
+
+int mfvi_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            const int32_t* t_applied, const double* loss_d, const float* loss_f, float weight_decay, void* stream)
+{
+    if (n < 0 || !t_applied || weight_decay < 0.f) { set_error("adamw_step_guarded: bad arguments"); return -1; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps, 0.f, 0.f,
+                       1.0f - lr * weight_decay, lr, StepGuard{t_applied, loss_d, loss_f});
+    return (int)hipGetLastError();
+}
+
+int mfvi_step_advance(int32_t* t_applied, const double* loss_d, const float* loss_f, void* stream)
+{
+    if (!t_applied) { set_error("step_advance: null counter"); return -1; }
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_applied, StepGuard{t_applied, loss_d, loss_f});
+    return (int)hipGetLastError();
+}
+
+int mfvi_decimate(const float* src, int H, int W, int factor, float* dst, void* stream)
+{
+    if (!src || !dst || factor < 1 || H < factor || W < factor) { set_error("decimate: bad arguments"); return -1; }
+    const int h = H / factor, w = W / factor;
+    hipLaunchKernelGGL(decimate_kernel, dim3(nblocks((long long)h * w)), dim3(256), 0, (hipStream_t)stream, src, W, factor, h, w, dst);
     return (int)hipGetLastError();
 }
 
@@ -639,7 +789,7 @@ int mfvi_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f - lr * weight_decay);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), 1.0f - lr * weight_decay, lr, StepGuard{nullptr, nullptr, nullptr});
     return (int)hipGetLastError();
 }
 

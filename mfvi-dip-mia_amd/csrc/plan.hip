@@ -433,6 +433,9 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
         const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
         if (rc) { set_error("backward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
+    // one use per draw: the parameters are updated in place in the same buffers, so a later backward with the same counters (a second
+    // backward through a retained graph, a caller re-using a step index after an optimizer step) must re-draw from what mu / rho hold now
+    plan->samp_n = 0;
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
     std::vector<GradFinEntry> fin; int fin_blocks = 0;      // layers whose dW went to partial slabs in this pass
     // side stream for the backward-weight kernels (MFVI_SIDE_STREAM=0: everything on the caller's stream)

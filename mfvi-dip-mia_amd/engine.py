@@ -60,6 +60,7 @@ class ElboEngine:
         self.dout = torch.empty_like(self.out)
         self.acc = torch.zeros(4, dtype=torch.float64, device=dev)        # [0] nll sum, [1] kl
         self.upd_scratch = torch.zeros(L.lib().mfvi_elbo_update_scratch_bytes(), dtype=torch.uint8, device=dev)
+        self.t_applied = torch.zeros(1, dtype=torch.int32, device=dev)    # CT: optimizer steps actually taken (the NaN guard skips some)
         self.sr_factor = sr_factor
         self.theta = None
         if task == TASK_CT:
@@ -84,7 +85,7 @@ class ElboEngine:
         for b in self.prog.bns:
             self.bn[b["off"]:b["off"] + b["C"]] = 1.0
         L.check(lib.mfvi_uniform_fill(self.seed, 0, 0, 0, self.z0.numel(), 0.1, L.ptr(self.z0), sp))
-        self.m.zero_(); self.v.zero_(); self.t = 0
+        self.m.zero_(); self.v.zero_(); self.t = 0; self.t_applied.zero_()
 
     def set_target(self, target, mask=None):
         """den: noisy image [H][W]; sr: low-res image [H/f][W/f]; ct: sinogram [T][W]; inp: colour image [3][H][W] with
@@ -155,9 +156,22 @@ class ElboEngine:
         lib, sp = L.lib(), L.stream_ptr()
         self.grad_only(self.t, with_kl=False)
         self.t += 1
+        if self.task == TASK_CT:
+            # `if not torch.isnan(loss): optimizer.step()` (bayesian_optimization.py:581-582) decided on the device: no host sync
+            L.check(lib.mfvi_elbo_update_guarded(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi, self.n_bn, 0.0,
+                                                 self.prior_sigma, self.temp, self.lr, 0.9, 0.999, 1e-8, L.ptr(self.t_applied), *self._guard(),
+                                                 L.ptr(self.acc[1:]), L.ptr(self.upd_scratch), sp))
+            return
         L.check(lib.mfvi_elbo_update(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi, self.n_bn, 0.0,
                                      self.prior_sigma, self.temp, self.lr, 0.9, 0.999, 1e-8, self.t, L.ptr(self.acc[1:]),
                                      L.ptr(self.upd_scratch), sp))
+
+    def _guard(self):
+        """(loss_d, loss_f) of the NaN guard: the local double accumulator, or the float that rode the all-reduce when K is sharded
+        (every rank then takes the same decision)."""
+        if self.world > 1:
+            return None, L.ptr(self.grads[self.n_params:])
+        return L.ptr(self.acc), None
 
     def losses(self):
         """(nll, kl, loss) of the last grad_only/step — forces a device sync."""
@@ -208,7 +222,7 @@ class SiblingEngine(ElboEngine):
         for b in self.prog.bns:
             self.bn[b["off"]:b["off"] + b["C"]] = 1.0
         L.check(lib.mfvi_uniform_fill(self.seed, 0, 0, 0, self.z0.numel(), 0.1, L.ptr(self.z0), sp))
-        self.m.zero_(); self.v.zero_(); self.t = 0
+        self.m.zero_(); self.v.zero_(); self.t = 0; self.t_applied.zero_()
 
     def _loss_and_dout(self, n):
         lib, sp = L.lib(), L.stream_ptr()
@@ -239,8 +253,14 @@ class SiblingEngine(ElboEngine):
         self.t += 1
         n = self.n_vi
         for lo, hi in ((0, n), (2 * n, self.n_params)):          # MU block and BN block; RHO does not exist for these methods
-            L.check(lib.mfvi_adamw_step(L.ptr(self.params[lo:]), L.ptr(self.grads[lo:]), L.ptr(self.m[lo:]), L.ptr(self.v[lo:]), hi - lo,
-                                        self.lr, 0.9, 0.999, 1e-8, self.t, self.weight_decay, sp))
+            if self.task == TASK_CT:                              # NaN guard of the CT runners (bayesian_optimization.py:380, 792, 994)
+                L.check(lib.mfvi_adamw_step_guarded(L.ptr(self.params[lo:]), L.ptr(self.grads[lo:]), L.ptr(self.m[lo:]), L.ptr(self.v[lo:]), hi - lo,
+                                                    self.lr, 0.9, 0.999, 1e-8, L.ptr(self.t_applied), *self._guard(), self.weight_decay, sp))
+            else:
+                L.check(lib.mfvi_adamw_step(L.ptr(self.params[lo:]), L.ptr(self.grads[lo:]), L.ptr(self.m[lo:]), L.ptr(self.v[lo:]), hi - lo,
+                                            self.lr, 0.9, 0.999, 1e-8, self.t, self.weight_decay, sp))
+        if self.task == TASK_CT:
+            L.check(lib.mfvi_step_advance(L.ptr(self.t_applied), *self._guard(), sp))
         if self.method == METHOD_SGLD and self.lr > 1e-8:        # scheduler.step() while get_last_lr() > 1e-8 (:1784-1785)
             self.lr *= self.gamma
 

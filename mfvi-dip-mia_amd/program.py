@@ -115,8 +115,9 @@ class Plan:
         search is written there), e.g. to keep a profiled run free of the search's launches."""
         import json, os, torch
         n = n_samples or self.max_samples
-        sig = "%d:%s" % (n, ";".join("%d,%d,%d,%d,%d" % (o["type"], o["ksize"], o["stride"], self.prog.tensors[o["out"]]["C"],
-                                                         self.prog.tensors[o["out"]]["H"] * self.prog.tensors[o["out"]]["W"]) for o in self.prog.ops))
+        T = self.prog.tensors
+        sig = "%d:%s" % (n, ";".join("%d,%d,%d,%d>%d,%dx%d" % (o["type"], o["ksize"], o["stride"], T[o["in1"] if o["in0"] < 0 else o["in0"]]["C"],
+                                                               T[o["out"]]["C"], T[o["out"]]["H"], T[o["out"]]["W"]) for o in self.prog.ops))
         cache = cache or os.environ.get("MFVI_TUNE_CACHE")
         if cache and os.path.exists(cache):
             try:

@@ -62,20 +62,27 @@ def _load_image(img, imsize, seed):
 
 
 class _Book:
-    """Device-side bookkeeping state of one fit."""
+    """Device-side bookkeeping state of one den / sr / ct fit (bayesian_optimization.py:1374-1416, :2190-2236, :584-626).
+    Column 0 of mse_noisy / psnrs / ssims is the 'corrupted' reference of the task: the noisy image (den), the low-resolution image
+    against the [::f, ::f] projection of the output (sr: downsampler(out_avg) / out_lr, :2203-2218), the ground truth (ct)."""
 
-    def __init__(self, eng, num_iter, gt, noisy_or_none):
+    def __init__(self, eng, num_iter, gt, noisy_or_none, task="den", factor=4):
         import torch
         self.t = torch
         H, W, C = eng.H, eng.W, eng.out.shape[1]
         dev = "cuda"
-        self.C, self.H, self.W = C, H, W
+        self.C, self.H, self.W, self.task, self.f = C, H, W, task, int(factor)
         self.ema = torch.zeros((C, H, W), device=dev)
         self.out_clip = torch.zeros((H, W), device=dev); self.ale_clip = torch.zeros((H, W), device=dev); self.avg_clip = torch.zeros((H, W), device=dev)
         self.ring_epi = torch.zeros((MC_ITER, H, W), device=dev); self.ring_ale = torch.zeros((MC_ITER, H, W), device=dev)
         self.metrics = torch.zeros((num_iter, 8), dtype=torch.float64, device=dev)     # mse_noisy, mse_gt, 3 psnr-mse, 3 ssim sums
-        self.gt = torch.from_numpy(gt).to(dev); self.noisy = None if noisy_or_none is None else torch.from_numpy(noisy_or_none).to(dev)
+        self.gt = torch.from_numpy(np.ascontiguousarray(gt, np.float32)).to(dev)
+        self.noisy = None if noisy_or_none is None else torch.from_numpy(np.ascontiguousarray(noisy_or_none, np.float32)).to(dev)
         self.var = torch.zeros((H, W), device=dev); self.ale_mean = torch.zeros((H, W), device=dev)
+        if task == "sr":      # img_small_torch = downsampler(img_torch) and the projections of out_avg / out (:2101, :2203, :2207)
+            h, w = H // self.f, W // self.f
+            self.gt_lr = self.gt[::self.f, ::self.f].contiguous()
+            self.avg_lr = torch.zeros((h, w), device=dev); self.out_lr_clip = torch.zeros((h, w), device=dev)
 
     def iteration(self, eng, i, n, lr_view=None):
         lib, sp, p = L.lib(), L.stream_ptr(), L.ptr
@@ -84,14 +91,22 @@ class _Book:
                                   p(self.avg_clip), p(self.ring_epi[slot]), p(self.ring_ale[slot]) if self.C > 1 else None, sp))
         m = self.metrics[i]
         hw = self.H * self.W
-        ref_noisy = self.noisy if self.noisy is not None else self.gt
         avg0 = self.ema[0]
-        L.check(lib.mfvi_sq_err_sum(p(avg0), p(ref_noisy), hw, p(m[0:]), sp))           # mse(out_avg[:, :1], noisy)  :1389
+        if self.task == "sr":
+            h, w = self.gt_lr.shape
+            L.check(lib.mfvi_decimate(p(avg0), self.H, self.W, self.f, p(self.avg_lr), sp))
+            L.check(lib.mfvi_decimate(p(self.out_clip), self.H, self.W, self.f, p(self.out_lr_clip), sp))     # clip and [::f, ::f] commute
+            L.check(lib.mfvi_sq_err_sum(p(self.avg_lr), p(self.gt_lr), h * w, p(m[0:]), sp))         # mse(downsampler(out_avg)[:, :1], img_small)  :2203
+            L.check(lib.mfvi_sq_err_sum(p(self.gt_lr), p(self.out_lr_clip), h * w, p(m[2:]), sp))    # psnr_lr                                       :2214
+            L.check(lib.mfvi_ssim_sum(p(self.gt_lr), p(self.out_lr_clip), h, w, p(m[5:]), sp))       # ssim_lr                                       :2217
+        else:
+            ref_noisy = self.noisy if self.noisy is not None else self.gt                            # ct: both columns against the ground truth (:594-606)
+            L.check(lib.mfvi_sq_err_sum(p(avg0), p(ref_noisy), hw, p(m[0:]), sp))                    # mse(out_avg[:, :1], noisy)  :1389
+            L.check(lib.mfvi_sq_err_sum(p(ref_noisy), p(self.out_clip), hw, p(m[2:]), sp))           # psnr_corrupted              :1398
+            L.check(lib.mfvi_ssim_sum(p(ref_noisy), p(self.out_clip), self.H, self.W, p(m[5:]), sp))
         L.check(lib.mfvi_sq_err_sum(p(avg0), p(self.gt), hw, p(m[1:]), sp))              # mse(out_avg[:, :1], gt)     :1390
-        L.check(lib.mfvi_sq_err_sum(p(ref_noisy), p(self.out_clip), hw, p(m[2:]), sp))   # psnr_corrupted              :1398
         L.check(lib.mfvi_sq_err_sum(p(self.gt), p(self.out_clip), hw, p(m[3:]), sp))     # psnr_gt
         L.check(lib.mfvi_sq_err_sum(p(self.gt), p(self.avg_clip), hw, p(m[4:]), sp))     # psnr_gt_sm
-        L.check(lib.mfvi_ssim_sum(p(ref_noisy), p(self.out_clip), self.H, self.W, p(m[5:]), sp))
         L.check(lib.mfvi_ssim_sum(p(self.gt), p(self.out_clip), self.H, self.W, p(m[6:]), sp))
         L.check(lib.mfvi_ssim_sum(p(self.gt), p(self.avg_clip), self.H, self.W, p(m[7:]), sp))
 
@@ -103,12 +118,62 @@ class _Book:
         return self.var.cpu().numpy(), self.ale_mean.cpu().numpy(), self.avg_clip.cpu().numpy()
 
     def results(self):
-        m = self.metrics.cpu().numpy(); hw = self.H * self.W
-        mse_noisy, mse_gt = m[:, 0] / hw, m[:, 1] / hw
+        m = self.metrics.cpu().numpy(); hw = float(self.H * self.W)
+        n = np.full(8, hw)
+        if self.task == "sr":
+            n[[0, 2, 5]] = float(self.gt_lr.numel())
+        m = m / n
         with np.errstate(divide="ignore"):
-            psnrs = 10.0 * np.log10(1.0 / (m[:, 2:5] / hw))
-        ssims = m[:, 5:8] / hw
-        return mse_noisy, mse_gt, psnrs, ssims
+            psnrs = 10.0 * np.log10(1.0 / m[:, 2:5])
+        return m[:, 0], m[:, 1], psnrs, m[:, 5:8]
+
+
+class _BookInp:
+    """Device-side bookkeeping of the inpainting runner (bayesian_optimization.py:3039-3090): sigmoid colour channels, masked PSNR / SSIM."""
+
+    def __init__(self, eng, num_iter, img, mask):
+        import torch
+        dev = "cuda"
+        H, W = eng.H, eng.W
+        self.H, self.W = H, W
+        self.img = torch.from_numpy(np.ascontiguousarray(img, np.float32)).to(dev)
+        self.mask = torch.from_numpy(np.ascontiguousarray(mask, np.float32)).to(dev).round()
+        self.mc = self.mask.shape[0]
+        self.ema = torch.zeros((4, H, W), device=dev)
+        self.out_clip = torch.zeros((3, H, W), device=dev); self.avg_clip = torch.zeros_like(self.out_clip); self.ale_clip = torch.zeros((H, W), device=dev)
+        self.img_m = torch.zeros_like(self.out_clip); self.out_m = torch.zeros_like(self.out_clip); self.avg_m = torch.zeros_like(self.out_clip)
+        self.ring_epi = torch.zeros((MC_ITER, 3, H, W), device=dev); self.ring_ale = torch.zeros((MC_ITER, H, W), device=dev)
+        self.metrics = torch.zeros((num_iter, 10, 3), dtype=torch.float64, device=dev)      # per channel: mse, 3 psnr-mse, 3 ssim sums (+ spare)
+        self.var = torch.zeros((3, H, W), device=dev); self.ale_mean = torch.zeros((H, W), device=dev)
+
+    def iteration(self, eng, i, n):
+        lib, p, sp = L.lib(), L.ptr, L.stream_ptr()
+        H, W = self.H, self.W; HW = H * W; slot = i % MC_ITER
+        L.check(lib.mfvi_bookkeep_inpainting(p(eng.out), n, H, W, p(self.img), p(self.mask), self.mc, p(self.ema), EXP_WEIGHT, int(i == 0),
+                                             p(self.out_clip), p(self.ale_clip), p(self.avg_clip), p(self.img_m), p(self.out_m), p(self.avg_m),
+                                             p(self.ring_epi[slot]), p(self.ring_ale[slot]), sp))
+        m = self.metrics[i]
+        for c in range(3):                                            # channel-wise sums; means over the 3 channels taken on the host
+            L.check(lib.mfvi_sq_err_sum(p(self.ema[c]), p(self.img[c]), HW, p(m[0, c:]), sp))            # mse(out_avg[:, :3], img)        :3051-3052
+            L.check(lib.mfvi_sq_err_sum(p(self.img[c]), p(self.out_clip[c]), HW, p(m[1, c:]), sp))       # psnr_corrupted                  :3062
+            L.check(lib.mfvi_sq_err_sum(p(self.img_m[c]), p(self.out_m[c]), HW, p(m[2, c:]), sp))        # psnr_gt (masked)                :3063
+            L.check(lib.mfvi_sq_err_sum(p(self.img_m[c]), p(self.avg_m[c]), HW, p(m[3, c:]), sp))        # psnr_gt_sm
+            L.check(lib.mfvi_ssim_sum(p(self.img[c]), p(self.out_clip[c]), H, W, p(m[4, c:]), sp))
+            L.check(lib.mfvi_ssim_sum(p(self.img_m[c]), p(self.out_m[c]), H, W, p(m[5, c:]), sp))
+            L.check(lib.mfvi_ssim_sum(p(self.img_m[c]), p(self.avg_m[c]), H, W, p(m[6, c:]), sp))
+
+    def snapshot(self):
+        lib, p, sp = L.lib(), L.ptr, L.stream_ptr()
+        for c in range(3):
+            L.check(lib.mfvi_ring_stats(p(self.ring_epi[:, c].contiguous()), MC_ITER, self.H, self.W, p(self.var[c]), None, sp))
+        L.check(lib.mfvi_ring_stats(p(self.ring_ale), MC_ITER, self.H, self.W, None, p(self.ale_mean), sp))
+        return self.var.cpu().numpy(), self.ale_mean.cpu().numpy(), self.avg_clip.cpu().numpy()
+
+    def results(self):
+        mt = self.metrics.cpu().numpy().mean(axis=2) / (self.H * self.W)      # mean over the colour channels == mean over all 3*H*W elements
+        with np.errstate(divide="ignore"):
+            psnrs = 10.0 * np.log10(1.0 / mt[:, 1:4])
+        return mt[:, 0], mt[:, 0], psnrs, mt[:, 4:7]                          # the reference computes both MSEs against img_torch (:3051-3052)
 
 
 def _make_engine(method, H, W, task, K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, **kw):
@@ -156,12 +221,12 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
         target = sino
         extra["img_radon"] = sino.cpu().numpy()[None, None]
     eng.set_target(torch.from_numpy(target) if isinstance(target, np.ndarray) else target)
-    book = _Book(eng, num_iter, img_np, noisy)
+    book = _Book(eng, num_iter, img_np, noisy, task=task, factor=factor)
     n_snap = num_iter // show_every + 1
     recons = np.zeros((n_snap, 1, H, W)); uncerts_epi = np.zeros((n_snap, 1, H, W)); uncerts_ale = np.zeros((n_snap, 1, H, W))
     t0 = time.perf_counter()
     for i in range(num_iter):
-        eng.step()                                                    # one fused ELBO iteration (CT keeps the NaN guard inside step)
+        eng.step()                                                    # one fused ELBO iteration (a non-finite loss skips the update on the device: engine.step)
         book.iteration(eng, i, eng.chunk)
         if i % show_every == 0:
             var, ale, recon = book.snapshot()
@@ -174,9 +239,13 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
     if save:
         wrap = lambda a: {method: a}                                  # MSE_CORRUPTED['mfvi'] / ['dip'] / ['mcd'] / ['sgld'] of the reference
         unc = (lambda a: {}) if method == "dip" else wrap            # run_*_dip leaves UNCERTS_EPI / UNCERTS_ALE empty (:1126-1127, :1230-1232)
-        np.savez(os.path.join(run_dir, "save.npz"), img_gt=img_np, img_noisy=noisy if noisy is not None else img_np,
+        # first two keys as the reference writes them per task: den img_gt / img_noisy (:1438), sr img_hr / img_lr (:2258), ct img_gt / img_radon (:643)
+        # with the reference's shapes: get_image() arrays are (1, H, W), img_lr is squeezed, the CT tensors keep (1, 1, ., .)
+        head = dict(den=dict(img_gt=img_np[None], img_noisy=None if noisy is None else noisy[None]), sr=dict(img_hr=img_np[None], img_lr=extra.get("img_lr")),
+                    ct=dict(img_gt=img_np[None, None], img_radon=extra.get("img_radon")))[task]
+        np.savez(os.path.join(run_dir, "save.npz"), **head,
                  mse_noisy=wrap(mse_noisy), mse_gt=wrap(mse_gt), recons=wrap(recons), uncerts=unc(uncerts_epi), uncerts_ale=unc(uncerts_ale),
-                 psnrs=wrap(psnrs), ssims=wrap(ssims), **extra)
+                 psnrs=wrap(psnrs), ssims=wrap(ssims))
         with open(os.path.join(run_dir, "locals.txt"), "a") as f:
             print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
         if plot:
@@ -274,47 +343,21 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
     num_iter += 1                                                     # bayesian_optimization.py:2935
     eng = _make_engine(method, H, W, "inp", K, input_depth, temp, sigma, lr, seed, net_kwargs, dict(weight_decay=weight_decay, dropout_p=dropout_p, gamma=gamma))
     eng.set_target(torch.from_numpy(img_np), torch.from_numpy(mask_np))
-    dev = "cuda"; HW = H * W; mc = mask_np.shape[0]
-    ema = torch.zeros((4, H, W), device=dev)
-    out_clip = torch.zeros((3, H, W), device=dev); avg_clip = torch.zeros_like(out_clip); ale_clip = torch.zeros((H, W), device=dev)
-    img_m = torch.zeros_like(out_clip); out_m = torch.zeros_like(out_clip); avg_m = torch.zeros_like(out_clip)
-    ring_epi = torch.zeros((MC_ITER, 3, H, W), device=dev); ring_ale = torch.zeros((MC_ITER, H, W), device=dev)
-    metrics = torch.zeros((num_iter, 10, 3), dtype=torch.float64, device=dev)      # per channel: mse, 3 psnr-mse, 3 ssim sums (+ spare)
-    var = torch.zeros((3, H, W), device=dev); ale_mean = torch.zeros((H, W), device=dev)
+    book = _BookInp(eng, num_iter, img_np, mask_np)
     n_snap = num_iter // show_every + 1
     recons = np.zeros((n_snap, 3, H, W)); uncerts_epi = np.zeros((n_snap, 3, H, W)); uncerts_ale = np.zeros((n_snap, 1, H, W))
-    lib, p = L.lib(), L.ptr
-    img_d = eng.target
     t0 = time.perf_counter()
     for i in range(num_iter):
         eng.step()
-        sp = L.stream_ptr(); slot = i % MC_ITER
-        L.check(lib.mfvi_bookkeep_inpainting(p(eng.out), eng.chunk, H, W, p(img_d), p(eng.mask), mc, p(ema), EXP_WEIGHT, int(i == 0), p(out_clip), p(ale_clip),
-                                             p(avg_clip), p(img_m), p(out_m), p(avg_m), p(ring_epi[slot]), p(ring_ale[slot]), sp))
-        m = metrics[i]
-        for c in range(3):                                            # channel-wise sums; means over the 3 channels taken on the host
-            L.check(lib.mfvi_sq_err_sum(p(ema[c]), p(img_d[c]), HW, p(m[0, c:]), sp))            # mse(out_avg[:, :3], img)        :3051-3052
-            L.check(lib.mfvi_sq_err_sum(p(img_d[c]), p(out_clip[c]), HW, p(m[1, c:]), sp))       # psnr_corrupted                  :3062
-            L.check(lib.mfvi_sq_err_sum(p(img_m[c]), p(out_m[c]), HW, p(m[2, c:]), sp))          # psnr_gt (masked)                :3063
-            L.check(lib.mfvi_sq_err_sum(p(img_m[c]), p(avg_m[c]), HW, p(m[3, c:]), sp))          # psnr_gt_sm
-            L.check(lib.mfvi_ssim_sum(p(img_d[c]), p(out_clip[c]), H, W, p(m[4, c:]), sp))
-            L.check(lib.mfvi_ssim_sum(p(img_m[c]), p(out_m[c]), H, W, p(m[5, c:]), sp))
-            L.check(lib.mfvi_ssim_sum(p(img_m[c]), p(avg_m[c]), H, W, p(m[6, c:]), sp))
+        book.iteration(eng, i, eng.chunk)
         if i % show_every == 0:
-            for c in range(3):
-                L.check(lib.mfvi_ring_stats(p(ring_epi[:, c].contiguous()), MC_ITER, H, W, p(var[c]), None, sp))
-            L.check(lib.mfvi_ring_stats(p(ring_ale), MC_ITER, H, W, None, p(ale_mean), sp))
-            uncerts_epi[i // show_every] = var.cpu().numpy(); uncerts_ale[i // show_every, 0] = ale_mean.cpu().numpy()
-            recons[i // show_every] = avg_clip.cpu().numpy()
+            var, ale, recon = book.snapshot()
+            uncerts_epi[i // show_every] = var; uncerts_ale[i // show_every, 0] = ale; recons[i // show_every] = recon
             if verbose:
                 nll, kl, loss = eng.losses()
                 print("iter %6d  loss %.5f  nll %.5f  kl %.4e  (%.1f it/s)" % (i, loss, nll, kl, (i + 1) / (time.perf_counter() - t0)))
     torch.cuda.synchronize()
-    mt = metrics.cpu().numpy().mean(axis=2) / HW                      # mean over the colour channels == mean over all 3*H*W elements
-    mse_corrupted = mt[:, 0]; mse_gt = mt[:, 0]                       # the reference computes both against img_torch (:3051-3052)
-    with np.errstate(divide="ignore"):
-        psnrs = 10.0 * np.log10(1.0 / mt[:, 1:4])
-    ssims = mt[:, 4:7]
+    mse_corrupted, mse_gt, psnrs, ssims = book.results()
     if save:
         wrap = lambda a: {method: a}
         unc = (lambda a: {}) if method == "dip" else wrap            # run_inp_dip leaves UNCERTS_EPI / UNCERTS_ALE empty (:2884-2886)

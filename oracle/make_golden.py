@@ -145,11 +145,17 @@ SR = dict(temp=4.381719802264805e-07, sigma=4.9e-08)                   # test_co
 CT = dict(temp=2.2e-10, sigma=1.7e-7)                                  # test_configs/mfvi_ct.json
 
 
-def golden_net(name, onet, seed, K, task="den", full_arrays=True, dtype=torch.float32, save=True):
+def golden_net(name, onet, seed, K, task="den", full_arrays=True, dtype=torch.float32, save=True, compact=False, bf16=False):
+    """compact: the float64 twin's output and the eval-mode output are stored strided (the 256^2 fixtures stay small).
+    bf16: mu / rho are rounded to bfloat16 (round-to-nearest-even, O.bf16_round == torch's .bfloat16().float()) before they are loaded
+    into the reference's MeanFieldVI — the values a bf16 parameter store holds (BASELINE configs[4])."""
     cfg = dict(den=DEN, sr=SR, ct=CT)[task]
     temp = cfg["temp"]; prior_raw = float(np.sqrt(temp) * cfg["sigma"])
     conv, bn, n_vi, n_bnp = O.net_table(onet)
     mu, rho, bnp = test_params(onet, seed)
+    if bf16:
+        assert np.array_equal(O.bf16_round(mu), torch.from_numpy(mu).bfloat16().float().numpy())
+        mu, rho = O.bf16_round(mu), O.bf16_round(rho)
     net = build_ref_net(onet, prior_raw)
     load_flat(net, mu, rho, bnp, conv, bn)
     net = net.to(dtype)      # float64 run of the same reference code = noise-free anchor for the gradients
@@ -165,6 +171,8 @@ def golden_net(name, onet, seed, K, task="den", full_arrays=True, dtype=torch.fl
         fr = R["radon"].FastRadonTransform((1, 1, H, W), theta)
         sino_t = fr(torch.from_numpy(img)[None, None]).detach()
         res["sino_target"] = sino_t.numpy()[0, 0]
+        if dtype != torch.float32:      # the float64 twin: same fp32 sinogram target, transform and loss in float64
+            fr = fr.to(dtype); sino_t = sino_t.to(dtype)
     net.zero_grad()
     outs = []; nll_sum = 0.0
     with EpsInjector() as inj:
@@ -209,9 +217,12 @@ def golden_net(name, onet, seed, K, task="den", full_arrays=True, dtype=torch.fl
     if not save:
         return res
     if name.startswith("full"):
-        r64 = golden_net(name, onet, seed, K, task, full_arrays=False, dtype=torch.float64, save=False)
+        r64 = golden_net(name, onet, seed, K, task, full_arrays=False, dtype=torch.float64, save=False, bf16=bf16)
         for kname in ("dmu_s", "drho_s", "dbn", "dmu_layer_norm", "drho_layer_norm", "out", "nll"):
             res[kname + "_f64"] = np.asarray(r64[kname], np.float64)
+        if compact:
+            res["out_s_f64"] = strided(res.pop("out_f64"), 16384); res["out_eval_s"] = strided(res.pop("out_eval"), 16384)
+            res["out"] = res["out"].astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **res)
     print(name, "nll", nll_sum, "kl", float(kl), "out", res["out"].shape, "|dmu|", np.linalg.norm(dmu), "|drho|", np.linalg.norm(drho))
 
@@ -544,8 +555,99 @@ def golden_inp_dip_loss():
     print("inp dip loss", res["loss1"], res["loss3"])
 
 
+def golden_bookkeeping():
+    """The runners' per-iteration bookkeeping with torch ops in the reference's order and the reference's own PSNR / SSIM
+    (utils/common_utils.py:297-353; bayesian_optimization.py itself is not importable: cv2 / gpytorch):
+      den  bayesian_optimization.py:1374-1416   (2 channels, noisy + gt metrics)
+      sr   :2190-2236                           (metrics of the low-resolution projection in column 0)
+      ct   :584-626                             (1 channel, no aleatoric map)
+      inp  :3039-3090                           (sigmoid colour channels, masked PSNR / SSIM)
+    Inputs are synthetic raw network outputs regenerated from seeds by the tests; 28 iterations > 25 ring slots, so the ring
+    wraps, and the snapshot at iteration 10 sees the ring's still-zero slots like the reference's torch.var over all 25."""
+    psnr, ssim = R["cu"].peak_signal_noise_ratio, R["cu"].structural_similarity
+    mse = torch.nn.MSELoss()
+    n_it, w, mc_iter = 28, 0.99, 25
+    res = dict(n_it=n_it, snap=np.array([10, 27]))
+    for task, (H, W, C) in dict(den=(32, 40, 2), sr=(32, 48, 2), ct=(24, 32, 1)).items():
+        seed = dict(den=61, sr=62, ct=63)[task]
+        img = O.phantom(H, W, seed); noisy = O.noisy(img, 0.1, seed)
+        img_t = torch.from_numpy(img)[None, None]; noisy_t = torch.from_numpy(noisy)[None, None]
+        down = lambda x: torch.nn.functional.interpolate(x, scale_factor=0.25, mode='nearest', recompute_scale_factor=False)
+        small_t = down(img_t)
+        ring_epi = torch.zeros((mc_iter, H, W)); ring_ale = torch.zeros((mc_iter, H, W))
+        out_avg = None
+        M = np.zeros((n_it, 8)); snaps = {}
+        for i in range(n_it):
+            raw = bookkeeping_raw(task, seed, i, img, C)
+            out = torch.from_numpy(raw.copy())[None]
+            out_lr = down(out)
+            if C > 1:
+                out[:, 1:] = torch.exp(-out[:, 1:])
+            out_avg = out.detach() if out_avg is None else out_avg * w + out.detach() * (1 - w)
+            _out = out[:, :1].clip(0, 1); _out_avg = out_avg[:, :1].clip(0, 1)
+            ring_epi[i % mc_iter] = _out[0]
+            if C > 1:
+                ring_ale[i % mc_iter] = out[:, 1:].clip(0, 1)[0]
+            if task == "den":
+                M[i] = [mse(out_avg[:, :1], noisy_t).item(), mse(out_avg[:, :1], img_t).item(),
+                        psnr(noisy_t, _out), psnr(img_t, _out), psnr(img_t, _out_avg), ssim(noisy_t, _out), ssim(img_t, _out), ssim(img_t, _out_avg)]
+            elif task == "sr":
+                _out_lr = out_lr[:, :1].clip(0, 1)
+                M[i] = [mse(down(out_avg)[:, :1], small_t).item(), mse(out_avg[:, :1], img_t).item(),
+                        psnr(small_t, _out_lr), psnr(img_t, _out), psnr(img_t, _out_avg), ssim(small_t, _out_lr), ssim(img_t, _out), ssim(img_t, _out_avg)]
+            else:
+                m0 = mse(out_avg[:, :1], img_t).item(); p0 = psnr(img_t, _out); s0 = ssim(img_t, _out)
+                M[i] = [m0, m0, p0, p0, psnr(img_t, _out_avg), s0, s0, ssim(img_t, _out_avg)]
+            if i in (10, 27):
+                snaps[i] = (torch.var(ring_epi, dim=0).numpy().copy(), torch.mean(ring_ale, dim=0).numpy().copy(), _out_avg[0, 0].numpy().copy())
+        res.update({task + "_metrics": M, task + "_ema": out_avg[0].numpy(), task + "_shape": np.array([H, W, C])})
+        for i, (v, a, r) in snaps.items():
+            res.update({"%s_var%d" % (task, i): v, "%s_ale%d" % (task, i): a, "%s_recon%d" % (task, i): r})
+    # inpainting
+    H, W, seed = 24, 32, 64
+    img = np.stack([O.phantom(H, W, seed + c) for c in range(3)])
+    img_t = torch.from_numpy(img)[None]
+    for mc in (1, 3):
+        mask = (O.uniform_fill(seed, 2 + mc, 0, 0, mc * H * W).reshape(1, mc, H, W) > 0.3).astype(np.float32)
+        mask_t = torch.from_numpy(mask)
+        ring_epi = torch.zeros((mc_iter, 3, H, W)); ring_ale = torch.zeros((mc_iter, H, W))
+        out_avg = None; M = np.zeros((n_it, 8)); snaps = {}
+        for i in range(n_it):
+            raw = bookkeeping_raw("inp", seed, i, img, 4)
+            out = torch.from_numpy(raw.copy())[None]
+            out_pred = out[:, :3].sigmoid()
+            out[:, :3] = out_pred
+            out[:, 3:] = torch.exp(-out[:, 3:])
+            out_avg = out.detach() if out_avg is None else out_avg * w + out.detach() * (1 - w)
+            _out = out[:, :3].clip(0, 1); _out_avg = out_avg[:, :3].clip(0, 1); _out_ale = out[:, 3:].clip(0, 1)
+            ring_epi[i % mc_iter] = _out[0]; ring_ale[i % mc_iter] = _out_ale[0]
+            m0 = mse(out_avg[:, :3], img_t).item()
+            M[i] = [m0, m0, psnr(img_t, _out), psnr(img_t * mask_t, _out * mask_t), psnr(img_t * mask_t, _out_avg * mask_t),
+                    ssim(img_t, _out), ssim(img_t * mask_t, _out * mask_t), ssim(img_t * mask_t, _out_avg * mask_t)]
+            if i in (10, 27):
+                snaps[i] = (torch.var(ring_epi, dim=0).numpy().copy(), torch.mean(ring_ale, dim=0).numpy().copy(), _out_avg[0].numpy().copy())
+        res.update({"inp%d_metrics" % mc: M, "inp%d_ema" % mc: out_avg[0].numpy(), "inp_shape": np.array([H, W, 4])})
+        for i, (v, a, r) in snaps.items():
+            res.update({"inp%d_var%d" % (mc, i): v, "inp%d_ale%d" % (mc, i): a, "inp%d_recon%d" % (mc, i): r})
+    np.savez_compressed(os.path.join(GOLD, "bookkeeping.npz"), **res)
+    print("bookkeeping ok: den psnr_gt_sm[-1] %.4f, inp1 psnr %.4f" % (res["den_metrics"][-1, 4], res["inp1_metrics"][-1, 4]))
+
+
+def bookkeeping_raw(task, seed, i, img, C):
+    """Synthetic raw network output of iteration i, regenerated identically by tests/test_gpu_bookkeeping.py (oracle.bookkeeping_raw)."""
+    return O.bookkeeping_raw(task, seed, i, img, C)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--fullsize" in sys.argv:        # BASELINE configs 2-4 at 256^2 (strided) + the bf16-parameter twin of the 128^2 den net
+        golden_net("full_den_256_k1", O.make_net(256, 256), seed=1, K=1, task="den", full_arrays=False, compact=True)
+        golden_net("full_sr256_d32_k1", O.make_net(256, 256, input_depth=32), seed=2, K=1, task="sr", full_arrays=False, compact=True)
+        golden_net("full_ct_256_k1", O.make_net(256, 256, n_out=1), seed=1, K=1, task="ct", full_arrays=False, compact=True)
+        golden_net("full_den_128_k1_bf16", O.make_net(128, 128), seed=1, K=1, task="den", full_arrays=False, bf16=True)
+        sys.exit(0)
+    if "--bookkeeping" in sys.argv:
+        golden_bookkeeping(); sys.exit(0)
     if "--inp-dip" in sys.argv:
         golden_inp_dip_loss(); sys.exit(0)
     if "--siblings" in sys.argv:
@@ -565,3 +667,4 @@ if __name__ == "__main__":
     golden_inpainting()
     golden_siblings()
     golden_inp_dip_loss()
+    golden_bookkeeping()

@@ -385,3 +385,117 @@ def phantom(H, W, seed):
 def noisy(img, p_sigma, seed):
     rng = np.random.default_rng(seed + 1)
     return np.clip(img + rng.normal(scale=p_sigma, size=img.shape), 0, 1).astype(np.float32)
+
+
+# ---- the runners' per-iteration bookkeeping (numpy float32 restatement) ------------------------
+def bookkeeping_raw(task, seed, i, img, C, k=0):
+    """Synthetic raw network output of iteration i, MC sample k (values leave [0, 1] so the clips matter)."""
+    img = np.asarray(img, np.float32)
+    H, W = img.shape[-2:]
+    nz = normal_fill(seed, 2, 20 + i, k, 0, C * H * W).reshape(C, H, W)
+    out = np.empty((C, H, W), np.float32)
+    if task == "inp":
+        out[:3] = 3.0 * (img - 0.5) + 0.5 * nz[:3]
+        out[3] = 1.0 + nz[3]
+    else:
+        out[0] = img + 0.2 * nz[0]
+        if C > 1:
+            out[1] = 1.5 + nz[1]
+    return out
+
+
+class Bookkeeper:
+    """EMA / clips / 25-slot ring buffers / metrics of the MFVI runners, float32 like the reference's torch code, with the build's
+    K-sample generalisation (`out` := mean over the K samples of [out_k[:1], exp(-out_k[1:])]; K = 1 is the reference):
+    den bayesian_optimization.py:1374-1416, sr :2190-2236, ct :584-626, inp :3039-3090."""
+
+    def __init__(self, task, H, W, gt, noisy=None, mask=None, factor=4, weight=0.99, mc_iter=25):
+        self.task, self.H, self.W, self.f, self.w, self.R = task, H, W, factor, np.float32(weight), mc_iter
+        self.gt = np.asarray(gt, np.float32); self.noisy = None if noisy is None else np.asarray(noisy, np.float32)
+        self.mask = None if mask is None else np.asarray(mask, np.float32)
+        nc = 3 if task == "inp" else 1
+        self.ring_epi = np.zeros((mc_iter, nc, H, W), np.float32); self.ring_ale = np.zeros((mc_iter, H, W), np.float32)
+        self.ema = None; self.i = 0
+
+    @staticmethod
+    def _psnr(a, b):
+        return 10.0 * np.log10(1.0 / np.mean((a.astype(np.float32) - b.astype(np.float32)).astype(np.float64) ** 2))
+
+    @staticmethod
+    def _ssim(a, b):
+        a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+        if a.ndim == 2:
+            return ssim(a, b)
+        return float(np.mean([ssim(a[c], b[c]) for c in range(a.shape[0])]))
+
+    def step(self, outs):
+        """outs: [K][C][H][W] raw network outputs of this iteration -> the 8 numbers the runner stores
+        (mse_corrupted, mse_gt, 3 PSNR, 3 SSIM)."""
+        outs = np.asarray(outs, np.float32); K = outs.shape[0]
+        one = np.float32(1.0)
+        nim = 3 if self.task == "inp" else 1
+        tr = (lambda x: (one / (one + np.exp(-x))).astype(np.float32)) if self.task == "inp" else (lambda x: x)
+        m = np.zeros((nim, self.H, self.W), np.float32)
+        for k in range(K):
+            m += tr(outs[k, :nim])
+        m /= np.float32(K)
+        chans = [m]
+        a = None
+        if outs.shape[1] > nim:
+            a = np.zeros((1, self.H, self.W), np.float32)
+            for k in range(K):
+                a += np.exp(-outs[k, nim:nim + 1]).astype(np.float32)
+            a /= np.float32(K)
+            chans.append(a)
+        out = np.concatenate(chans, 0)
+        self.ema = out.copy() if self.ema is None else (self.ema * self.w + out * (one - self.w)).astype(np.float32)
+        _out = np.clip(out[:nim], 0, 1); _avg = np.clip(self.ema[:nim], 0, 1)
+        slot = self.i % self.R
+        self.ring_epi[slot] = _out
+        if a is not None:
+            self.ring_ale[slot] = np.clip(a[0], 0, 1)
+        self.i += 1
+        mse_ = lambda x, y: float(np.mean((x.astype(np.float32) - y.astype(np.float32)).astype(np.float64) ** 2))
+        gt = self.gt if self.task == "inp" else self.gt[None]
+        if self.task == "den":
+            nz = self.noisy[None]
+            return [mse_(self.ema[:1], nz), mse_(self.ema[:1], gt), self._psnr(nz, _out), self._psnr(gt, _out), self._psnr(gt, _avg),
+                    self._ssim(nz[0], _out[0]), self._ssim(gt[0], _out[0]), self._ssim(gt[0], _avg[0])]
+        if self.task == "sr":
+            f = self.f
+            small = gt[:, ::f, ::f]
+            # out_lr is the projection of the RAW output (channel 0 is untouched by the exp): mean over samples of out_k[0, ::f, ::f]
+            _lr = np.clip(m[:, ::f, ::f], 0, 1)
+            return [mse_(self.ema[:1, ::f, ::f], small), mse_(self.ema[:1], gt), self._psnr(small, _lr), self._psnr(gt, _out), self._psnr(gt, _avg),
+                    self._ssim(small[0], _lr[0]), self._ssim(gt[0], _out[0]), self._ssim(gt[0], _avg[0])]
+        if self.task == "ct":
+            m0 = mse_(self.ema[:1], gt); p0 = self._psnr(gt, _out); s0 = self._ssim(gt[0], _out[0])
+            return [m0, m0, p0, p0, self._psnr(gt, _avg), s0, s0, self._ssim(gt[0], _avg[0])]
+        mk = self.mask
+        m0 = mse_(self.ema[:3], gt)
+        return [m0, m0, self._psnr(gt, _out), self._psnr(gt * mk, _out * mk), self._psnr(gt * mk, _avg * mk),
+                self._ssim(gt, _out), self._ssim(gt * mk, _out * mk), self._ssim(gt * mk, _avg * mk)]
+
+    def snapshot(self):
+        """-> (unbiased variance of the epistemic ring over all R slots, mean of the aleatoric ring, clipped EMA image)."""
+        nim = 3 if self.task == "inp" else 1
+        var = np.var(self.ring_epi.astype(np.float64), axis=0, ddof=1).astype(np.float32)
+        ale = np.mean(self.ring_ale.astype(np.float64), axis=0).astype(np.float32)
+        return (var if nim == 3 else var[0]), ale, np.clip(self.ema[:nim], 0, 1) if nim == 3 else np.clip(self.ema[0], 0, 1)
+
+
+# ---- bfloat16 parameter storage (BASELINE configs[4]) ------------------------------------------
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even) -> float32; NaN-free inputs."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def bf16_bits(x):
+    """float32 array holding bf16-representable values -> uint16 bit patterns."""
+    return (np.ascontiguousarray(x, np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def bf16_from_bits(b):
+    return (np.ascontiguousarray(b, np.uint16).astype(np.uint32) << 16).view(np.float32)

@@ -68,15 +68,15 @@ def test_runner_artifacts(M, tmp_path):
     for key, shape in [("mse_noisy", (25,)), ("mse_gt", (25,)), ("psnrs", (25, 3)), ("ssims", (25, 3)), ("recons", (6, 1, 64, 64)),
                        ("uncerts", (6, 1, 64, 64)), ("uncerts_ale", (6, 1, 64, 64))]:
         assert z[key].flat[0]["mfvi"].shape == shape, key
-    assert z["img_gt"].shape == (64, 64) and z["img_noisy"].shape == (64, 64)
+    assert z["img_gt"].shape == (1, 64, 64) and z["img_noisy"].shape == (1, 64, 64)          # get_image() arrays: (1, H, W)
     assert os.path.exists(os.path.join(r["run_dir"], "locals.txt"))
     ps, ss = z["psnrs"].flat[0]["mfvi"], z["ssims"].flat[0]["mfvi"]
     assert np.isfinite(ps).all() and np.isfinite(ss).all()
     # metrics kernels vs the oracle on the stored snapshot of the smoothed reconstruction (iteration 20 = snapshot 4)
     rec = z["recons"].flat[0]["mfvi"][4, 0].astype(np.float32)
-    assert abs(O.psnr(z["img_gt"], rec) - ps[20, 2]) < 1e-3
-    assert abs(O.ssim(z["img_gt"], rec) - ss[20, 2]) < 1e-4
-    assert abs(float(np.mean((rec - z["img_gt"]) ** 2)) - 10 ** (-ps[20, 2] / 10)) < 1e-6
+    assert abs(O.psnr(z["img_gt"][0], rec) - ps[20, 2]) < 1e-3
+    assert abs(O.ssim(z["img_gt"][0], rec) - ss[20, 2]) < 1e-4
+    assert abs(float(np.mean((rec - z["img_gt"][0]) ** 2)) - 10 ** (-ps[20, 2] / 10)) < 1e-6
     # the fit moves: PSNR of the smoothed output improves over the first 25 iterations
     assert ps[-1, 2] > ps[0, 2]
     r2 = M.runner.run_ct_mfvi(img="phantom", imsize=(32, 32), num_iter=4, lr=1e-3, temp=2.2e-10, sigma=1.7e-7, input_depth=8, seed=1, show_every=2,
@@ -84,8 +84,13 @@ def test_runner_artifacts(M, tmp_path):
     z2 = np.load(os.path.join(r2["run_dir"], "save.npz"), allow_pickle=True)
     assert z2["img_radon"].shape == (1, 1, 45, 32) and np.isfinite(z2["psnrs"].flat[0]["mfvi"]).all()
     r3 = M.runner.run_sr_mfvi(img="phantom", imsize=(64, 64), num_iter=4, lr=1e-3, temp=4.4e-7, sigma=4.9e-8, input_depth=8, seed=2, show_every=2,
-                              save=False, K=2, net_kwargs=SMALL)
+                              save=True, save_path=str(tmp_path), K=2, net_kwargs=SMALL)
     assert np.isfinite(r3["psnrs"]).all()
+    z3 = np.load(os.path.join(r3["run_dir"], "save.npz"), allow_pickle=True)           # the SR runner's keys (bayesian_optimization.py:2258-2260)
+    assert set(z3.files) == {"img_hr", "img_lr", "mse_noisy", "mse_gt", "recons", "uncerts", "uncerts_ale", "psnrs", "ssims"}
+    assert z3["img_hr"].shape == (1, 64, 64) and z3["img_lr"].shape == (16, 16)
+    # column 0 is the low-resolution metric (psnr_lr / mse of the projection), not a copy of the ground-truth column
+    assert not np.allclose(r3["psnrs"][:, 0], r3["psnrs"][:, 1]) and not np.allclose(r3["mse_noisy"], r3["mse_gt"])
 
 
 def test_inpainting_runner_artifacts(M, tmp_path):

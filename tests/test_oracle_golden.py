@@ -117,7 +117,17 @@ NETS = {
     "small_ct_k1": (dict(H=32, W=32, input_depth=8, n_out=1, nd=(8, 16), nu=(8, 16), ns=(4, 4)), 2),
     "full_den_64_k1": (dict(H=64, W=64), 0),
     "full_den_128_k1": (dict(H=128, W=128), 0),
+    # BASELINE configs[1] / [2] / [3] nets at 256^2 (strided fixtures) and the bf16-parameter twin of the 128^2 den net (configs[4])
+    "full_den_256_k1": (dict(H=256, W=256), 0),
+    "full_sr256_d32_k1": (dict(H=256, W=256, input_depth=32), 1),
+    "full_ct_256_k1": (dict(H=256, W=256, n_out=1), 2),
+    "full_den_128_k1_bf16": (dict(H=128, W=128), 0),
 }
+
+
+def _strided(a, n=4096):
+    a = np.asarray(a).ravel(); st = max(1, a.size // n)
+    return a[::st][:n]
 
 
 @pytest.mark.parametrize("name", list(NETS))
@@ -127,6 +137,8 @@ def test_net_elbo_grad(golden_dir, name):
     net = O.make_net(**kw)
     seed, K = int(g["seed"]), int(g["K"])
     mu, rho, bnp = _golden_params(net, seed)
+    if name.endswith("_bf16"):
+        mu, rho = O.bf16_round(mu), O.bf16_round(rho)          # the values a bf16 parameter store holds
     H, W = net.H, net.W
     z = (0.1 * O.uniform_fill(seed, 0, 0, 0, net.input_depth * H * W)).reshape(net.input_depth, H, W)
     img = O.phantom(H, W, seed); tgt = O.noisy(img, 0.1, seed)
@@ -143,7 +155,9 @@ def test_net_elbo_grad(golden_dir, name):
     assert abs(r["nll"] - float(g["nll"])) < 3e-5 * abs(float(g["nll"]))
     assert abs(r["kl"] - float(g["kl"])) < 1e-6 * abs(float(g["kl"]))
     assert abs(r["loss"] - float(g["loss"])) < 3e-5 * abs(float(g["loss"]))
-    gt = 5e-5
+    # gradient tolerance vs the float64 twin.  SR at 256^2 back-propagates through 1/16 of the pixels and CT through a 45-angle sinogram:
+    # one LeakyReLU-kink flip weighs more there (the fp32 REFERENCE itself is 7e-3 / 1.4e-4 off its float64 twin on these two)
+    gt = {"full_sr256_d32_k1": 6e-4, "full_ct_256_k1": 3e-4}.get(name, 5e-5)
     if "dmu" in g.files:
         assert relerr(r["dmu"], g["dmu"]) < gt and relerr(r["drho"], g["drho"]) < gt
         assert relerr(r["dbn"], g["dbn"]) < gt
@@ -156,15 +170,22 @@ def test_net_elbo_grad(golden_dir, name):
         ln = np.array([np.linalg.norm(r["dmu"][int(c[4]):int(c[5]) + int(c[1])]) for c in conv])
         assert relerr(ds_, g["dmu_s_f64"]) < gt and relerr(rs_, g["drho_s_f64"]) < gt
         assert relerr(ln, g["dmu_layer_norm_f64"]) < gt and relerr(r["dbn"], g["dbn_f64"]) < gt
-        assert relerr(r["out"], g["out_f64"]) < 1e-5
-        assert relerr(ds_, g["dmu_s"]) < 5e-3 and relerr(rs_, g["drho_s"]) < 5e-3 and relerr(r["dbn"], g["dbn"]) < 5e-3
+        if "out_f64" in g.files:
+            assert relerr(r["out"], g["out_f64"]) < 1e-5
+        else:
+            assert relerr(_strided(r["out"], 16384), g["out_s_f64"]) < 1e-5
+        ft = 1.5e-2 if name == "full_sr256_d32_k1" else 5e-3
+        assert relerr(ds_, g["dmu_s"]) < ft and relerr(rs_, g["drho_s"]) < ft and relerr(r["dbn"], g["dbn"]) < ft
     # per-layer KL (VIModule._kl) and the RNG-free eval anchor
     conv, _, _, _ = O.net_table(net)
     pl = [O.kl(mu[int(c[4]):int(c[5]) + int(c[1])], rho[int(c[4]):int(c[5]) + int(c[1])], float(g["prior_sigma"])) for c in conv]
     assert relerr(pl, g["per_layer_kl"]) < 1e-6
     out_eval, tape = O.net_forward(net, mu, rho, bnp, z, seed, 0, 0, sample_weights=False)
     tape.free()
-    assert relerr(out_eval, g["out_eval"]) < RTOL
+    if "out_eval" in g.files:
+        assert relerr(out_eval, g["out_eval"]) < RTOL
+    else:
+        assert relerr(_strided(out_eval, 16384), g["out_eval_s"]) < RTOL
 
 
 @pytest.mark.parametrize("name", ["traj_small_k1", "traj_small_k2"])
@@ -289,3 +310,37 @@ def test_inp_dip_loss(golden_dir):
         v, d = O.mse_sigmoid_masked(g["out%d" % mc], g["img%d" % mc], g["mask%d" % mc], 1.0, want_grad=True)
         assert abs(v - float(g["loss%d" % mc])) < 1e-6 * abs(float(g["loss%d" % mc]))
         assert relerr(d, g["grad%d" % mc]) < 1e-5 and np.all(d[3] == 0)
+
+
+def _bookkeeping_case(g, task):
+    """(Bookkeeper, per-iteration raw outputs [n_it][1][C][H][W]) of one golden bookkeeping case."""
+    if task.startswith("inp"):
+        H, W, C = [int(v) for v in g["inp_shape"]]; seed = 64; mc = int(task[3:])
+        img = np.stack([O.phantom(H, W, seed + c) for c in range(3)])
+        mask = (O.uniform_fill(seed, 2 + mc, 0, 0, mc * H * W).reshape(mc, H, W) > 0.3).astype(np.float32)
+        bk = O.Bookkeeper("inp", H, W, img, mask=mask)
+        raws = [O.bookkeeping_raw("inp", seed, i, img, 4)[None] for i in range(int(g["n_it"]))]
+        return bk, raws
+    H, W, C = [int(v) for v in g[task + "_shape"]]; seed = dict(den=61, sr=62, ct=63)[task]
+    img = O.phantom(H, W, seed)
+    bk = O.Bookkeeper(task, H, W, img, noisy=O.noisy(img, 0.1, seed))
+    return bk, [O.bookkeeping_raw(task, seed, i, img, C)[None] for i in range(int(g["n_it"]))]
+
+
+@pytest.mark.parametrize("task", ["den", "sr", "ct", "inp1", "inp3"])
+def test_bookkeeping(golden_dir, task):
+    """The oracle's restatement of the runners' bookkeeping (EMA 0.99, clips, 25-slot rings, unbiased var, LR metrics of the SR
+    runner, masked metrics of the inpainting runner) against the reference's torch ops / PSNR / SSIM (bookkeeping.npz)."""
+    g = load(golden_dir, "bookkeeping")
+    bk, raws = _bookkeeping_case(g, task)
+    M = g[task + "_metrics"]
+    for i, raw in enumerate(raws):
+        row = bk.step(raw)
+        assert relerr(row, M[i]) < 5e-5, (task, i, row, M[i])
+        if i in (10, 27):
+            var, ale, recon = bk.snapshot()
+            assert relerr(var, g["%s_var%d" % (task, i)]) < 2e-5
+            assert relerr(recon, g["%s_recon%d" % (task, i)]) < 1e-6
+            if task != "ct":
+                assert relerr(ale, g["%s_ale%d" % (task, i)]) < 1e-6
+    assert relerr(bk.ema, g[task + "_ema"]) < 1e-6
