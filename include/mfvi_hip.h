@@ -33,6 +33,7 @@ typedef struct mfvi_plan mfvi_plan;
 enum { MFVI_OP_CONV = 1, MFVI_OP_CONCAT_UP = 2 };
 enum { MFVI_UP_BILINEAR = 0, MFVI_UP_NEAREST = 1 };   /* nn.Upsample(scale_factor=2, mode=...) (models/skip.py:102) */
 enum { MFVI_TASK_DENOISE = 0, MFVI_TASK_SR = 1 };
+enum { MFVI_PARAM_F32 = 0, MFVI_PARAM_BF16 = 1 };     /* storage of the MU / RHO blocks (mfvi_plan_set_param_dtype) */
 
 /* An activation tensor of the layer program, [C][H][W] per MC sample, stored RAW (conv output or
  * concat result).  Consumers read view(T) = LeakyReLU?(BatchNorm_train?(T)): the BatchNorm2d (training
@@ -78,17 +79,24 @@ int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled);
 /* Dropout2d layers of the program are active by default (the reference keeps its MC-dropout nets in train mode);
  * enabled = 0 makes them the identity (nn.Dropout2d in eval mode). */
 int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled);
+/* bfloat16 storage of mu / rho (BASELINE configs[4]: "bf16 mu/rho with fp32 KL accumulate"; the reference keeps float32 Parameters:
+ * BayTorch/modules/module.py:45-62).  With MFVI_PARAM_BF16 the `mu` / `rho` arguments of mfvi_forward / mfvi_backward / mfvi_plan_autotune
+ * point to arrays of n_vi bf16 values (uint16_t: the upper half of the float32 pattern); the reparameterisation draw reads them directly
+ * (half the parameter bytes per pass) and every value computed from them — sampled weights, activations, gradients, KL — is float32
+ * exactly as with float32 storage of the same (bf16-representable) numbers.  Gradients, Adam moments and the BatchNorm block stay
+ * float32.  The update rule is mfvi_elbo_update_bf16: no float32 master copy, stochastic rounding.  mu and rho must be 8-byte aligned. */
+int mfvi_plan_set_param_dtype(mfvi_plan* plan, int dtype);
 /* bytes of caller-provided device workspace (activations, gradients, BN statistics) for max_samples */
 int64_t mfvi_plan_workspace_bytes(const mfvi_plan* plan);
 
 /* n_samples MC forwards of the net on the SAME input z[Cin][H][W]; sample i uses eps of global sample
  * index k0+i.  sample_weights = 0 reproduces RTLayer's eval branch (w = mu).  out: [n_samples][Cout][H][W]. */
-int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z,
+int mfvi_forward(mfvi_plan* plan, const void* mu, const void* rho, const float* bn, const float* z,
                  uint64_t seed, uint32_t step, uint32_t k0, int n_samples, int sample_weights,
                  void* workspace, float* out, void* stream);
 /* Backward of the same call (workspace must still hold its activations).  dout: [n_samples][Cout][H][W].
  * dmu/drho/dbn are ACCUMULATED into (+=).  dz (optional): [n_samples][Cin][H][W]. */
-int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z,
+int mfvi_backward(mfvi_plan* plan, const void* mu, const void* rho, const float* bn, const float* z,
                   uint64_t seed, uint32_t step, uint32_t k0, int n_samples, int sample_weights,
                   void* workspace, const float* dout, float* dmu, float* drho, float* dbn, float* dz, void* stream);
 /* Debug/parity access: copy tensor `tensor_id` of sample `sample` from the workspace to dst (device):
@@ -108,7 +116,7 @@ int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* o
  * fastest per (op, pass).  Tilings do not change any result (same accumulation order per output element).
  * out_scratch: 2 * n_samples * numel(output tensor) floats; grad_scratch: 2 * n_vi + n_bn floats.  Synchronises `stream`.
  * Contents of workspace / scratch are undefined afterwards.  MFVI_AUTOTUNE=0 in the environment makes this a no-op. */
-int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, int n_samples,
+int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const float* bn, const float* z, int n_samples,
                        void* workspace, float* out_scratch, float* grad_scratch, void* stream);
 /* Tiling in use for conv op `op`: which 0 forward, 1 backward-data (mf | th << 8 | T << 16), 2 backward-weight
  * (input tiles | waves << 8 | block target/256 << 16); 0 = built-in heuristic. */
@@ -161,6 +169,18 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int64_t mfvi_elbo_update_scratch_bytes(void);
 int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma,
                      float temp, float lr, float beta1, float beta2, float eps, int t, double* kl_out, void* scratch, void* stream);
+/* mfvi_elbo_update for bf16 mu / rho: mu_bf16 / rho_bf16 = n_vi bf16 values each, bn = the float32 BatchNorm block; grads / m / v
+ * keep the float32 layout [MU | RHO | BN].  KL terms and the gradient in float32 on the values the bf16 parameters denote, KL summed in
+ * float64, Adam in float32; the new mu / rho are rounded to bf16 STOCHASTICALLY (an fp32 master copy would double the parameter state;
+ * round-to-nearest would freeze rho: lr = 1e-3 against ulp_bf16(-3) = 1.6e-2): magnitude rounded up with probability
+ * (discarded 16 bits) / 2^16, the 16-bit word = upper half of lane j & 3 of Philox block j >> 2, RNG domain 6, stream 0 (MU) / 1 (RHO),
+ * sample 0, step t — deterministic and reproducible on the CPU (oracle/). */
+int mfvi_elbo_update_bf16(void* mu_bf16, void* rho_bf16, float* bn, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu,
+                          float prior_sigma, float temp, float lr, float beta1, float beta2, float eps, int t, uint64_t seed, double* kl_out,
+                          void* scratch, void* stream);
+/* bf16 <-> float32 copies of n values (float32 -> bf16 rounds to nearest even) */
+int mfvi_bf16_to_f32(const void* src, int64_t n, float* dst, void* stream);
+int mfvi_f32_to_bf16(const float* src, int64_t n, void* dst, void* stream);
 /* The CT runners' NaN guard, `if not torch.isnan(loss): optimizer.step()` (bayesian_optimization.py:380, 581-582, 792, 994), without a host
  * sync.  loss = data term + temp * KL, and KL is a function of the parameters alone (finite while every earlier update was), so the guard
  * reads the DATA-TERM scalar of this iteration on the device: loss_d (the double accumulator of mfvi_radon_mse & co) and / or loss_f (the

@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmfvi_hip.so")
 
 OP_CONV, OP_CONCAT_UP = 1, 2
-DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD, DOMAIN_DROPOUT = 0, 1, 2, 3, 4, 5
+DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD, DOMAIN_DROPOUT, DOMAIN_ROUND = 0, 1, 2, 3, 4, 5, 6
+PARAM_F32, PARAM_BF16 = 0, 1
 
 
 class TensorDesc(C.Structure):
@@ -33,6 +34,7 @@ SIGNATURES = {
     "mfvi_plan_destroy": (None, [_P]),
     "mfvi_plan_workspace_bytes": (_I64, [_P]),
     "mfvi_plan_set_dropout": (_I, [_P, _I]),
+    "mfvi_plan_set_param_dtype": (_I, [_P, _I]),
     "mfvi_plan_set_side_stream": (_I, [_P, _I]),
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
     "mfvi_backward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -58,6 +60,9 @@ SIGNATURES = {
     "mfvi_adamw_step_guarded": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _P, _P, _F, _P]),
     "mfvi_step_advance": (_I, [_P, _P, _P, _P]),
     "mfvi_decimate": (_I, [_P, _I, _I, _I, _P, _P]),
+    "mfvi_elbo_update_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _U64, _P, _P, _P]),
+    "mfvi_bf16_to_f32": (_I, [_P, _I64, _P, _P]),
+    "mfvi_f32_to_bf16": (_I, [_P, _I64, _P, _P]),
     "mfvi_adamw_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "mfvi_mse_sigmoid_masked": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_mse_channel": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),

@@ -85,7 +85,7 @@ __device__ __forceinline__ void spec_boxmuller(uint32_t a, uint32_t b, float& z0
     z1 = rad * sn;
 }
 
-enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4, DOMAIN_DROPOUT = 5 };
+enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4, DOMAIN_DROPOUT = 5, DOMAIN_ROUND = 6 };
 
 struct RngKey {              // everything but the block index
     uint32_t k0, k1;         // seed lo/hi
@@ -103,6 +103,36 @@ __device__ __forceinline__ void spec_normal4(const RngKey& key, uint32_t blk, fl
 }
 
 #pragma clang fp contract(fast)
+
+// bfloat16 parameter storage (mu / rho of BASELINE configs[4]): the upper 16 bits of the float32 pattern
+typedef uint16_t bf16_t;
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float((uint32_t)b << 16);
+#else
+    union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f;
+#endif
+}
+__device__ __forceinline__ float4 bf16x4_to_f32(const bf16_t* p)      // 8-byte aligned quad
+{
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+}
+// round to nearest even (NaN-free parameters)
+__device__ __forceinline__ bf16_t f32_to_bf16_rne(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+// stochastic rounding: round the magnitude up with probability (discarded bits) / 2^16, `r16` uniform in [0, 2^16); unbiased, so
+// Adam updates far below one bf16 ulp (lr 1e-3 against ulp(rho = -3) = 1.6e-2) still move the parameter in expectation
+__device__ __forceinline__ bf16_t f32_to_bf16_sr(float f, uint32_t r16)
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (bf16_t)(u >> 16);       // inf / NaN pass through
+    return (bf16_t)((u + (r16 & 0xffffu)) >> 16);
+}
 
 // torch.nn.functional.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -283,8 +313,11 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
                               int n_samples, hipStream_t st, const FoldFuse* fuse = nullptr);
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
-int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const float* mu, const float* rho, RngKey key,
-                          int n_samples, float* wsamp, long long wstride, hipStream_t st);
+// bf16: mu / rho point to bf16_t arrays; sample = 0 writes W = mu (RTLayer's eval branch) — callers then launch it for ONE sample
+int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const void* mu, const void* rho, RngKey key,
+                          int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16 = 0, int sample = 1);
+// bf16 -> float32 expansion (the generic fp32 kernels of shapes the MFMA path does not serve read float32 mu / rho)
+int launch_expand_bf16(const void* src, long long n, float* dst, hipStream_t st);
 constexpr int SAMPLE_QUADS = 256;       // weight quads per block of the sampling kernel
 // The MFMA backward-weight kernel writes per-(pixel strip, sample) partial sums of dW (and of the bias gradient) with plain
 // stores: part.base[(strip * n_samples + k) * part.stride + j], j < n_w weights then n_b biases; launch_grad_finalize reduces
@@ -294,9 +327,9 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
                                 hipStream_t st);
 struct GradFinEntry { long long w_off, b_off, part_off, stride; int n_w, n_b, strips, layer_id, first_block, pad; };
 // wsamp (optional): the sampled-weight slab of this pass, sample k at wsamp + k*wstride; then eps_k*softplus(rho) is read as W_k - mu
-int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
-                         int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const float* mu,
-                         hipStream_t st);
+int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const void* rho, RngKey key,
+                         int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const void* mu,
+                         hipStream_t st, int bf16 = 0);
 constexpr int GRAD_FIN_QUADS = 64;      // weight quads per block of the finalize kernel
 struct FoldSrc { const float* d; long long sstride; int pad; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.

@@ -3,6 +3,8 @@
 // AdamW(wd=0) (bayesian_optimization.py:1356-1357), RNG fills, per-iteration bookkeeping
 // (bayesian_optimization.py:1374-1406, utils/common_utils.py:297-353).
 #include "common.h"
+#include <algorithm>
+#include <type_traits>
 #include "../../include/mfvi_hip.h"
 
 namespace {
@@ -488,12 +490,16 @@ __device__ __forceinline__ int find_entry(const Entry* __restrict__ table, int n
 //   eps_k * softplus(rho) = W_k - mu, one float4 load instead of a Philox + 2 Box-Muller evaluation per quad and sample;
 // otherwise it is re-derived from the counter RNG (same key as the forward draw).  A block owns GRAD_FIN_QUADS quads of 4
 // consecutive weights of one layer; its 4 waves split the samples and are summed through LDS.
+template <bool BF16>
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* __restrict__ table, int n_entries,
-                                                            const float* __restrict__ part_base, const float* __restrict__ rho,
+                                                            const float* __restrict__ part_base, const void* __restrict__ rho_v,
                                                             RngKey key, int sample_weights, int n_samples,
                                                             float* __restrict__ dmu, float* __restrict__ drho,
-                                                            const float* __restrict__ wsamp, long long wstride, const float* __restrict__ mu)
+                                                            const float* __restrict__ wsamp, long long wstride, const void* __restrict__ mu_v)
 {
+    typedef typename std::conditional<BF16, bf16_t, float>::type PT;
+    const PT* __restrict__ rho = static_cast<const PT*>(rho_v); const PT* __restrict__ mu = static_cast<const PT*>(mu_v);
+    auto ld = [](const PT* q) -> float { if constexpr (BF16) return bf16_to_f32(*q); else return *q; };
     __shared__ float s_mu[3][GRAD_FIN_QUADS][4], s_rh[3][GRAD_FIN_QUADS][4];
     __shared__ int s_first[TABLE_LDS];
     const GradFinEntry e = table[find_entry(table, n_entries, (int)blockIdx.x, s_first)];
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
     const long long jq = (is_w ? e.w_off : e.b_off) + 4LL * quad;      // first parameter of the quad inside MU / RHO
     float mq[4] = {0.f, 0.f, 0.f, 0.f};
     if (from_slab && (is_w || is_b))
-        for (int l = 0; l < nv; ++l) mq[l] = mu[jq + l];
+        for (int l = 0; l < nv; ++l) mq[l] = ld(mu + jq + l);
     if (is_w || is_b) {
         const float* __restrict__ P = part_base + e.part_off + col;
         // the wave's samples in batches of 4, fully unrolled: the loads of a batch are independent, so up to 16 float4 are in
@@ -573,9 +579,9 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
         for (int l = 0; l < nv; ++l) {
             dmu[j0 + l] += am[l];
             if (from_slab) {         // ar = sum_k dW_k * (W_k - mu) = softplus(rho) * sum_k dW_k * eps_k, with the softplus the draw used
-                const float r = rho[j0 + l], sp = is_w ? softplus_fast(r) : softplus_f(r);
+                const float r = ld(rho + j0 + l), sp = is_w ? softplus_fast(r) : softplus_f(r);
                 drho[j0 + l] += ar[l] / sp * sigmoid_f(r);
-            } else if (sample_weights) drho[j0 + l] += ar[l] * sigmoid_f(rho[j0 + l]);
+            } else if (sample_weights) drho[j0 + l] += ar[l] * sigmoid_f(ld(rho + j0 + l));
         }
     }
 }
@@ -586,10 +592,13 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
 // eps_k from the counter RNG (domain EPS, stream 2*layer [+1 bias], sample k0+k, step); weights use the hardware-exp
 // softplus_fast, biases the libm-grade softplus_f — the same split the conv kernels used when they sampled in place.
 // grid: x = blocks of SAMPLE_QUADS quads over all layers of the table, y = sample.
+template <bool BF16>
 __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* __restrict__ table, int n_entries,
-                                                             const float* __restrict__ mu, const float* __restrict__ rho,
-                                                             RngKey key, float* __restrict__ wsamp, long long wstride)
+                                                             const void* __restrict__ mu_v, const void* __restrict__ rho_v,
+                                                             RngKey key, float* __restrict__ wsamp, long long wstride, int sample)
 {
+    typedef typename std::conditional<BF16, bf16_t, float>::type PT;
+    const PT* __restrict__ mu = static_cast<const PT*>(mu_v); const PT* __restrict__ rho = static_cast<const PT*>(rho_v);
     __shared__ int s_first[TABLE_LDS];
     const SampleEntry e = table[find_entry(table, n_entries, (int)blockIdx.x, s_first)];
     const int k = blockIdx.y;
@@ -598,25 +607,84 @@ __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* 
     if (item >= nq_w + nq_b) return;
     RngKey kw = key; kw.sample += (uint32_t)k;
     float* __restrict__ o = wsamp + (long long)k * wstride;
-    float z[4];
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (item < nq_w) {
         kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id);
-        spec_normal4(kw, (uint32_t)item, z);
+        if (sample) spec_normal4(kw, (uint32_t)item, z);
         const long long j = e.w_off + 4LL * item;
-        const float4 m = *reinterpret_cast<const float4*>(mu + j), r = *reinterpret_cast<const float4*>(rho + j);
-        float4 w;
-        w.x = __builtin_fmaf(softplus_fast(r.x), z[0], m.x); w.y = __builtin_fmaf(softplus_fast(r.y), z[1], m.y);
-        w.z = __builtin_fmaf(softplus_fast(r.z), z[2], m.z); w.w = __builtin_fmaf(softplus_fast(r.w), z[3], m.w);
+        float4 m, r;
+        if constexpr (BF16) { m = bf16x4_to_f32(mu + j); r = bf16x4_to_f32(rho + j); }
+        else { m = *reinterpret_cast<const float4*>(mu + j); r = *reinterpret_cast<const float4*>(rho + j); }
+        float4 w = m;
+        if (sample) {
+            w.x = __builtin_fmaf(softplus_fast(r.x), z[0], m.x); w.y = __builtin_fmaf(softplus_fast(r.y), z[1], m.y);
+            w.z = __builtin_fmaf(softplus_fast(r.z), z[2], m.z); w.w = __builtin_fmaf(softplus_fast(r.w), z[3], m.w);
+        }
         *reinterpret_cast<float4*>(o + j) = w;
     } else {
         const int q = item - nq_w;
         kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id + 1);
-        spec_normal4(kw, (uint32_t)q, z);
+        if (sample) spec_normal4(kw, (uint32_t)q, z);
         for (int l = 0; l < 4 && 4 * q + l < e.n_b; ++l) {
             const long long j = e.b_off + 4 * q + l;
-            o[j] = mu[j] + softplus_f(rho[j]) * z[l];
+            float mj, rj;
+            if constexpr (BF16) { mj = bf16_to_f32(mu[j]); rj = bf16_to_f32(rho[j]); } else { mj = mu[j]; rj = rho[j]; }
+            o[j] = sample ? mj + softplus_f(rj) * z[l] : mj;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void expand_bf16_kernel(const bf16_t* __restrict__ src, long long n, float* __restrict__ dst)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = bf16_to_f32(src[i]);
+}
+__global__ __launch_bounds__(256) void round_bf16_kernel(const float* __restrict__ src, long long n, bf16_t* __restrict__ dst)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = f32_to_bf16_rne(src[i]);
+}
+
+// ---- fused tail of an ELBO iteration on bf16 mu / rho (BASELINE configs[4]) ----
+// Same arithmetic as elbo_update_kernel on the float32 values the bf16 parameters denote: KL terms in fp32, summed in fp64; gradients,
+// both Adam moments and the update in fp32; the new mu / rho go back to bf16 by STOCHASTIC rounding with a 16-bit word of the counter
+// RNG: domain ROUND, stream 0 (MU) / 1 (RHO), element j = lane j & 3 of block j >> 2, sample 0, step = t (upper 16 bits of the word).
+// The BatchNorm parameters stay float32.
+__global__ __launch_bounds__(256) void elbo_update_bf16_kernel(bf16_t* __restrict__ pm, bf16_t* __restrict__ pr, float* __restrict__ bn, float* __restrict__ g, float* __restrict__ m,
+                                                               float* __restrict__ v, long long n_vi, long long n_bn, float m0, float s0, float temp,
+                                                               float b1, float b2, float eps, float step_size, float inv_sqrt_bc2, RngKey key,
+                                                               ElboUpdateScratch* __restrict__ sc)
+{
+    __shared__ double s_red[8];
+    const float log_s0 = logf(s0), s0sq = s0 * s0;
+    auto adam = [&](long long i, float gi, float pi) -> float {
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        return pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    };
+    double acc = 0;
+    const long long nq = (n_vi + 3) >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long long)gridDim.x * 256) {
+        uint32_t rm[4], rr[4];
+        RngKey k0 = key; k0.stream = ((uint32_t)DOMAIN_ROUND << 24) | 0u;
+        philox4x32_10((uint32_t)q, k0.stream, k0.sample, k0.step, k0.k0, k0.k1, rm);
+        philox4x32_10((uint32_t)q, k0.stream | 1u, k0.sample, k0.step, k0.k0, k0.k1, rr);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const long long i = 4 * q + l;
+            if (i >= n_vi) break;
+            const float mu = bf16_to_f32(pm[i]), r = bf16_to_f32(pr[i]);
+            const float s = softplus_f(r), d = mu - m0, inv = 1.f / s;
+            acc += (double)(logf(s) - log_s0) + (double)((s0sq + d * d) / (2.f * s * s)) - 0.5;
+            const float gmu = g[i] + temp * d * inv * inv;
+            const float grho = g[n_vi + i] + temp * (inv - (s0sq + d * d) * inv * inv * inv) * sigmoid_f(r);
+            g[i] = gmu; g[n_vi + i] = grho;
+            pm[i] = f32_to_bf16_sr(adam(i, gmu, mu), rm[l] >> 16);
+            pr[i] = f32_to_bf16_sr(adam(n_vi + i, grho, r), rr[l] >> 16);
+        }
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) bn[i] = adam(2 * n_vi + i, g[2 * n_vi + i], bn[i]);
+    const double tot = block_sum_d(acc, s_red);
+    if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
 }
 
 }  // namespace
@@ -628,21 +696,31 @@ int launch_dropout_masks(const DropEntry* table_dev, int n_entries, RngKey key, 
     return (int)hipGetLastError();
 }
 
-int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const float* mu, const float* rho, RngKey key,
-                          int n_samples, float* wsamp, long long wstride, hipStream_t st)
+int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const void* mu, const void* rho, RngKey key,
+                          int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16, int sample)
 {
     if (n_entries < 1 || n_blocks < 1) return 0;
-    hipLaunchKernelGGL(sample_weights_kernel, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride);
+    if (bf16) hipLaunchKernelGGL(sample_weights_kernel<true>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample);
+    else hipLaunchKernelGGL(sample_weights_kernel<false>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample);
     return (int)hipGetLastError();
 }
 
-int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const float* rho, RngKey key,
-                         int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const float* mu,
-                         hipStream_t st)
+int launch_expand_bf16(const void* src, long long n, float* dst, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(expand_bf16_kernel, dim3(nblocks(n)), dim3(256), 0, st, (const bf16_t*)src, n, dst);
+    return (int)hipGetLastError();
+}
+
+int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const void* rho, RngKey key,
+                         int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const void* mu,
+                         hipStream_t st, int bf16)
 {
     if (n_entries < 1 || n_blocks < 1) return 0;
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
-                       n_samples, dmu, drho, wsamp, wstride, mu);
+    if (bf16) hipLaunchKernelGGL(grad_finalize_kernel<true>, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
+                                 n_samples, dmu, drho, wsamp, wstride, mu);
+    else hipLaunchKernelGGL(grad_finalize_kernel<false>, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
+                            n_samples, dmu, drho, wsamp, wstride, mu);
     return (int)hipGetLastError();
 }
 
@@ -779,6 +857,37 @@ int mfvi_decimate(const float* src, int H, int W, int factor, float* dst, void* 
     if (!src || !dst || factor < 1 || H < factor || W < factor) { set_error("decimate: bad arguments"); return -1; }
     const int h = H / factor, w = W / factor;
     hipLaunchKernelGGL(decimate_kernel, dim3(nblocks((long long)h * w)), dim3(256), 0, (hipStream_t)stream, src, W, factor, h, w, dst);
+    return (int)hipGetLastError();
+}
+
+int mfvi_elbo_update_bf16(void* mu_bf16, void* rho_bf16, float* bn, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu,
+                          float prior_sigma, float temp, float lr, float beta1, float beta2, float eps, int t, uint64_t seed, double* kl_out, void* scratch,
+                          void* stream)
+{
+    if (!mu_bf16 || !rho_bf16 || !grads || !m || !v || !kl_out || !scratch || n_vi < 0 || n_bn < 0 || (n_bn > 0 && !bn) || t < 1 || !(prior_sigma > 0.f)) {
+        set_error("elbo_update_bf16: bad arguments (t is 1-based)"); return -1; }
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    const long long work = std::max<long long>((n_vi + 3) / 4, n_bn);
+    const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
+    hipLaunchKernelGGL(elbo_update_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (bf16_t*)mu_bf16, (bf16_t*)rho_bf16, bn, grads, m, v, (long long)n_vi,
+                       (long long)n_bn, prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)),
+                       make_key(seed, DOMAIN_ROUND, 0, 0, (uint32_t)t), (ElboUpdateScratch*)scratch);
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, (int*)nullptr,
+                       StepGuard{nullptr, nullptr, nullptr});
+    return (int)hipGetLastError();
+}
+
+int mfvi_bf16_to_f32(const void* src, int64_t n, float* dst, void* stream)
+{
+    if (n < 0 || (n > 0 && (!src || !dst))) { set_error("bf16_to_f32: bad arguments"); return -1; }
+    return launch_expand_bf16(src, (long long)n, dst, (hipStream_t)stream);
+}
+
+int mfvi_f32_to_bf16(const float* src, int64_t n, void* dst, void* stream)
+{
+    if (n < 0 || (n > 0 && (!src || !dst))) { set_error("f32_to_bf16: bad arguments"); return -1; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(round_bf16_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, src, (long long)n, (bf16_t*)dst);
     return (int)hipGetLastError();
 }
 

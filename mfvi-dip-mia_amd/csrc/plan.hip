@@ -54,6 +54,9 @@ struct mfvi_plan {
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
     SampleEntry* samp_dev = nullptr; int n_samp = 0, samp_blocks = 0;    // layers whose weights are drawn once per pass
     long long wsamp_off = -1;                  // floats: sampled weights [max_samples][n_vi]
+    int param_dtype = MFVI_PARAM_F32;          // storage of mu / rho handed to forward / backward (MFVI_PARAM_BF16: bf16_t arrays)
+    int n_generic = 0;                         // conv layers outside the sampling table (served by the generic fp32 kernels)
+    long long p32_off = -1;                    // floats: [mu | rho] expanded to float32 for those kernels when mu / rho are bf16
     // identity of the draw currently held in the sampled-weight slab (set by forward, reused by the matching backward)
     const void* samp_mu = nullptr; const void* samp_rho = nullptr; const void* samp_ws = nullptr;
     uint64_t samp_seed = 0; uint32_t samp_step = 0, samp_k0 = 0; int samp_n = 0;
@@ -202,6 +205,9 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
             samp.push_back(e);
         }
     p.n_samp = (int)samp.size();
+    for (auto& o : p.ops) if (o.d.type == MFVI_OP_CONV) ++p.n_generic;
+    p.n_generic -= p.n_samp;
+    if (p.n_generic > 0) p.p32_off = take(2 * p.n_vi);
     if (p.n_samp) {
         p.wsamp_off = take(p.n_vi * p.max_samples);
         hipError_t e = hipMalloc((void**)&p.samp_dev, sizeof(SampleEntry) * samp.size());
@@ -358,6 +364,13 @@ int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled)
     return 0;
 }
 
+int mfvi_plan_set_param_dtype(mfvi_plan* plan, int dtype)
+{
+    if (!plan || (dtype != MFVI_PARAM_F32 && dtype != MFVI_PARAM_BF16)) { set_error("set_param_dtype: bad arguments"); return -1; }
+    plan->param_dtype = dtype; plan->samp_n = 0;
+    return 0;
+}
+
 int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled)
 {
     if (!plan) { set_error("set_dropout: null plan"); return -1; }
@@ -365,31 +378,53 @@ int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled)
     return 0;
 }
 
-int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, uint64_t seed, uint32_t step,
+// float32 view of mu / rho for the generic kernels: the caller's arrays, or their expansion when the parameters are stored in bf16
+static int generic_params(mfvi_plan* plan, const Ctx& c, const void* mu, const void* rho, const float** mu32, const float** rho32, hipStream_t st)
+{
+    *mu32 = static_cast<const float*>(mu); *rho32 = static_cast<const float*>(rho);
+    if (plan->param_dtype != MFVI_PARAM_BF16) return 0;
+    *mu32 = nullptr; *rho32 = nullptr;
+    if (plan->n_generic <= 0) return 0;
+    float* dst = c.farena() + plan->p32_off;
+    int rc = launch_expand_bf16(mu, plan->n_vi, dst, st);
+    if (!rc) rc = launch_expand_bf16(rho, plan->n_vi, dst + plan->n_vi, st);
+    *mu32 = dst; *rho32 = dst + plan->n_vi;
+    return rc;
+}
+
+int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const float* bn, const float* z, uint64_t seed, uint32_t step,
                  uint32_t k0, int n_samples, int sample_weights, void* workspace, float* out, void* stream)
 {
     if (!check_call(plan, n_samples, workspace)) return -1;
-    if (!mu || !rho || !z || !out || (plan->n_bn > 0 && !bn)) { set_error("forward: null pointer argument"); return -1; }
+    if (!mu_v || !rho_v || !z || !out || (plan->n_bn > 0 && !bn)) { set_error("forward: null pointer argument"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     Ctx c{*plan, (char*)workspace, bn, z, n_samples};
+    const bool bf16 = plan->param_dtype == MFVI_PARAM_BF16;
+    if (bf16 && !use_mfma()) { set_error("forward: bf16 parameters need the MFMA path (MFVI_DISABLE_MFMA is set)"); return -1; }
+    if (bf16 && (((uintptr_t)mu_v | (uintptr_t)rho_v) & 7)) { set_error("forward: bf16 mu / rho must be 8-byte aligned"); return -1; }
+    const float* mu = nullptr; const float* rho = nullptr;
+    { const int rc = generic_params(plan, c, mu_v, rho_v, &mu, &rho, st); if (rc) { set_error("forward: bf16 expansion failed: %s", hipGetErrorString((hipError_t)rc)); return rc; } }
     if (plan->stats_doubles) {
         hipError_t e = hipMemsetAsync(c.fstats(), 0, sizeof(double) * plan->stats_doubles, st);
         if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
     // MFMA-served layers: draw every weight once per (layer, sample); without sampling the kernels read mu (stride 0)
-    const bool presample = use_mfma() && sample_weights && plan->n_samp > 0;
+    // (bf16 parameters: the slab also serves w = mu, as one float32 copy shared by all samples)
+    const bool presample = use_mfma() && (sample_weights || bf16) && plan->n_samp > 0;
     if (presample) {
         ProfScope ps(plan, -1, PASS_SAMPLE, st);
-        const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
+        const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu_v, rho_v, key, sample_weights ? n_samples : 1, c.wsamp(),
+                                             plan->n_vi, st, bf16, sample_weights);
         if (rc) { set_error("forward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
-        plan->samp_mu = mu; plan->samp_rho = rho; plan->samp_ws = workspace; plan->samp_seed = seed; plan->samp_step = step; plan->samp_k0 = k0; plan->samp_n = n_samples;
+        plan->samp_mu = mu_v; plan->samp_rho = rho_v; plan->samp_ws = workspace; plan->samp_seed = seed; plan->samp_step = step; plan->samp_k0 = k0;
+        plan->samp_n = sample_weights ? n_samples : -n_samples;
     }
     if (plan->n_drop && plan->dropout_on) {      // Dropout2d factors of this pass; the backward reads them from the workspace
         const int rc = launch_dropout_masks(plan->drop_dev, plan->n_drop, key, n_samples, c.farena(), st);
         if (rc) { set_error("forward: dropout mask launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
-    const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
+    const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = (presample && sample_weights) ? plan->n_vi : 0;
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         const OpInfo& o = plan->ops[i];
         const TensorInfo& y = plan->t[o.d.out];
@@ -400,6 +435,7 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
         ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV) {
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
+            if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); return -1; }
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
@@ -410,14 +446,19 @@ int mfvi_forward(mfvi_plan* plan, const float* mu, const float* rho, const float
     return 0;
 }
 
-int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, uint64_t seed, uint32_t step,
+int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const float* bn, const float* z, uint64_t seed, uint32_t step,
                   uint32_t k0, int n_samples, int sample_weights, void* workspace, const float* dout, float* dmu, float* drho,
                   float* dbn, float* dz, void* stream)
 {
     if (!check_call(plan, n_samples, workspace)) return -1;
-    if (!mu || !rho || !z || !dout || !dmu || !drho || (plan->n_bn > 0 && (!bn || !dbn))) { set_error("backward: null pointer argument"); return -1; }
+    if (!mu_v || !rho_v || !z || !dout || !dmu || !drho || (plan->n_bn > 0 && (!bn || !dbn))) { set_error("backward: null pointer argument"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     Ctx c{*plan, (char*)workspace, bn, z, n_samples};
+    const bool bf16 = plan->param_dtype == MFVI_PARAM_BF16;
+    if (bf16 && !use_mfma()) { set_error("backward: bf16 parameters need the MFMA path (MFVI_DISABLE_MFMA is set)"); return -1; }
+    if (bf16 && (((uintptr_t)mu_v | (uintptr_t)rho_v) & 7)) { set_error("backward: bf16 mu / rho must be 8-byte aligned"); return -1; }
+    const float* mu = nullptr; const float* rho = nullptr;
+    { const int rc = generic_params(plan, c, mu_v, rho_v, &mu, &rho, st); if (rc) { set_error("backward: bf16 expansion failed: %s", hipGetErrorString((hipError_t)rc)); return rc; } }
     if (plan->stats_doubles) {
         hipError_t e = hipMemsetAsync(c.bsums(), 0, sizeof(double) * plan->stats_doubles, st);
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
@@ -425,18 +466,19 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
     const RngKey key = base_key(seed, step, k0);
     // the weights of this pass: the slab still holds them when the preceding forward was this very pass (same parameter
     // buffers, counters, sample range and workspace); otherwise they are re-drawn from the same counters
-    const bool presample = use_mfma() && sample_weights && plan->n_samp > 0;
-    const bool held = plan->samp_mu == mu && plan->samp_rho == rho && plan->samp_ws == workspace && plan->samp_seed == seed &&
-                      plan->samp_step == step && plan->samp_k0 == k0 && plan->samp_n == n_samples;
+    const bool presample = use_mfma() && (sample_weights || bf16) && plan->n_samp > 0;
+    const bool held = plan->samp_mu == mu_v && plan->samp_rho == rho_v && plan->samp_ws == workspace && plan->samp_seed == seed &&
+                      plan->samp_step == step && plan->samp_k0 == k0 && plan->samp_n == (sample_weights ? n_samples : -n_samples);
     if (presample && !held) {
         ProfScope ps(plan, -1, PASS_SAMPLE, st);
-        const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu, rho, key, n_samples, c.wsamp(), plan->n_vi, st);
+        const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu_v, rho_v, key, sample_weights ? n_samples : 1, c.wsamp(),
+                                             plan->n_vi, st, bf16, sample_weights);
         if (rc) { set_error("backward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     // one use per draw: the parameters are updated in place in the same buffers, so a later backward with the same counters (a second
     // backward through a retained graph, a caller re-using a step index after an optimizer step) must re-draw from what mu / rho hold now
     plan->samp_n = 0;
-    const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = presample ? plan->n_vi : 0;
+    const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = (presample && sample_weights) ? plan->n_vi : 0;
     std::vector<GradFinEntry> fin; int fin_blocks = 0;      // layers whose dW went to partial slabs in this pass
     // side stream for the backward-weight kernels (MFVI_SIDE_STREAM=0: everything on the caller's stream)
     static const bool side_on = [] { const char* e = getenv("MFVI_SIDE_STREAM"); return !(e && e[0] == '0'); }();
@@ -485,6 +527,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                   fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS;
                   fin.push_back(e);
               }
+              if ((rc == -2 || rc == -3) && !mu) { set_error("backward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table", i); rc = -1; }
               if (rc == -2 || rc == -3) rc = launch_conv_bwd_weight(xin, gy, o.g, rho, key, sample_weights, dmu, drho, n_samples, sw); }
             const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
             if (!rc && need_dx) {
@@ -503,6 +546,7 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
                 if (!rc && !folded) {
                   ProfScope ps(plan, i, PASS_BWD_DATA, st);
                   rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, c.farena() + o.scratch_off, per, n_samples, st) : -2;
+                  if ((rc == -2 || rc == -3) && !mu) { set_error("backward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table", i); rc = -1; }
                   if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
                 if (!rc && !folded && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
                     FoldSrc srcs[2]; int ns = 0;
@@ -554,8 +598,8 @@ int mfvi_backward(mfvi_plan* plan, const float* mu, const float* rho, const floa
             plan->fin_uploaded = fin;
         }
         // every layer of `fin` (MFMA backward-weight) is also in the sampling table (same shape conditions), so its W_k sit in the slab
-        const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho, key, sample_weights, n_samples, dmu, drho,
-                                            presample && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu, st);
+        const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho_v, key, sample_weights, n_samples, dmu, drho,
+                                            presample && sample_weights && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu_v, st, bf16);
         if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     if (plan->n_entries) {
@@ -626,7 +670,7 @@ int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune)
     return 0;
 }
 
-int mfvi_plan_autotune(mfvi_plan* plan, const float* mu, const float* rho, const float* bn, const float* z, int n_samples,
+int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const float* bn, const float* z, int n_samples,
                        void* workspace, float* out_scratch, float* grad_scratch, void* stream)
 {
     if (!check_call(plan, n_samples, workspace)) return -1;

@@ -27,7 +27,7 @@ INP_NET = dict(nd=(16, 32, 64, 128, 128, 128), nu=(16, 32, 64, 128, 128, 128), n
 class ElboEngine:
     def __init__(self, H, W, task=TASK_DEN, K=1, input_depth=16, temp=1.0, sigma=0.1, lr=1e-3, seed=1, sr_factor=4,
                  theta_deg=None, rank=0, world_size=1, process_group=None, samples_per_launch=None, net_kwargs=None,
-                 autotune=True):
+                 autotune=True, param_dtype="f32"):
         import torch
         self.torch = torch
         self.task, self.K, self.H, self.W = task, int(K), H, W
@@ -43,16 +43,27 @@ class ElboEngine:
         kw.update(net_kwargs or {})
         self.prog, self.zin, self.zout, self.names = skip_program(H, W, input_depth, n_out, **kw)
         self.chunk = min(self.K_local, samples_per_launch or self.K_local)
-        self.plan = self.prog.compile(self.zin, self.zout, self.chunk)
+        self.param_dtype = param_dtype
+        self.plan = self.prog.compile(self.zin, self.zout, self.chunk, param_dtype=param_dtype)
         P = self.prog
         self.n_vi, self.n_bn = P.n_vi, P.n_bn
         self.n_params = 2 * P.n_vi + P.n_bn
         dev = "cuda"
-        self.params = torch.empty(self.n_params, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.n_params + 8, dtype=torch.float32, device=dev)     # [+8]: scalars riding the all-reduce
         self.m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
-        self.mu, self.rho, self.bn = self.params[:P.n_vi], self.params[P.n_vi:2 * P.n_vi], self.params[2 * P.n_vi:]
+        if param_dtype == "bf16":
+            # BASELINE configs[4]: mu / rho live in bfloat16 (no float32 master copy; stochastic rounding in the update), BN stays float32
+            if task == TASK_CT or type(self) is not ElboEngine:
+                raise NotImplementedError("bf16 parameter storage is built for the MFVI den / sr / inpainting engines")
+            pad = (P.n_vi + 7) // 8 * 8                                                   # the RHO block starts 8-byte aligned
+            self.params16 = torch.zeros(2 * pad, dtype=torch.bfloat16, device=dev)
+            self.mu, self.rho = self.params16[:P.n_vi], self.params16[pad:pad + P.n_vi]
+            self.bn = torch.empty(max(P.n_bn, 1), dtype=torch.float32, device=dev)[:P.n_bn]
+            self.params = None
+        else:
+            self.params = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+            self.mu, self.rho, self.bn = self.params[:P.n_vi], self.params[P.n_vi:2 * P.n_vi], self.params[2 * P.n_vi:]
         self.dmu, self.drho, self.dbn = self.grads[:P.n_vi], self.grads[P.n_vi:2 * P.n_vi], self.grads[2 * P.n_vi:self.n_params]
         self.z0 = torch.empty((input_depth, H, W), dtype=torch.float32, device=dev)
         self.z = torch.empty_like(self.z0)
@@ -79,8 +90,14 @@ class ElboEngine:
         """mu ~ N(0, 0.1), rho ~ N(-3, 0.1) (BayTorch/modules/module.py:26-30,56-62), BN gamma=1, beta=0;
         z0 = 0.1*U(0,1) (utils/common_utils.py:134-162).  Drawn from the RNG spec (domain INIT / UNIFORM)."""
         lib, sp = L.lib(), L.stream_ptr()
-        L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, 0, 0, 0, self.n_vi, 0.0, 0.1, L.ptr(self.mu), sp))
-        L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, 1, 0, 0, self.n_vi, -3.0, 0.1, L.ptr(self.rho), sp))
+        if self.param_dtype == "bf16":      # the float32 draw of the spec, rounded to nearest-even bf16
+            tmp = self.torch.empty(self.n_vi, dtype=self.torch.float32, device="cuda")
+            for stream_id, (a, b), dst in ((0, (0.0, 0.1), self.mu), (1, (-3.0, 0.1), self.rho)):
+                L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, stream_id, 0, 0, self.n_vi, a, b, L.ptr(tmp), sp))
+                L.check(lib.mfvi_f32_to_bf16(L.ptr(tmp), self.n_vi, L.ptr(dst), sp))
+        else:
+            L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, 0, 0, 0, self.n_vi, 0.0, 0.1, L.ptr(self.mu), sp))
+            L.check(lib.mfvi_normal_fill(self.seed, L.DOMAIN_INIT, 1, 0, 0, self.n_vi, -3.0, 0.1, L.ptr(self.rho), sp))
         self.bn.zero_()
         for b in self.prog.bns:
             self.bn[b["off"]:b["off"] + b["C"]] = 1.0
@@ -146,9 +163,22 @@ class ElboEngine:
             allreduce_sum_(self.grads, self.pg)
         if with_kl:
             # KL and its gradient are deterministic: every rank computes them redundantly (no communication)
-            L.check(lib.mfvi_kl(L.ptr(self.mu), L.ptr(self.rho), self.n_vi, 0.0, self.prior_sigma, L.ptr(self.acc[1:]), sp))
-            L.check(lib.mfvi_kl_backward(L.ptr(self.mu), L.ptr(self.rho), self.n_vi, 0.0, self.prior_sigma, self.temp,
+            mu, rho = self.mu, self.rho
+            if self.param_dtype == "bf16":      # the KL of the float32 values the bf16 parameters denote (step() fuses this into the update)
+                mu, rho = self.params_f32()[:2]
+            L.check(lib.mfvi_kl(L.ptr(mu), L.ptr(rho), self.n_vi, 0.0, self.prior_sigma, L.ptr(self.acc[1:]), sp))
+            L.check(lib.mfvi_kl_backward(L.ptr(mu), L.ptr(rho), self.n_vi, 0.0, self.prior_sigma, self.temp,
                                          L.ptr(self.dmu), L.ptr(self.drho), sp))
+
+    def params_f32(self):
+        """(mu, rho, bn) as float32 tensors: views of the parameter buffer, or the expansion of the bf16 blocks (mfvi_bf16_to_f32)."""
+        if self.param_dtype != "bf16":
+            return self.mu, self.rho, self.bn
+        lib, sp = L.lib(), L.stream_ptr()
+        out = self.torch.empty(2 * self.n_vi, dtype=self.torch.float32, device="cuda")
+        L.check(lib.mfvi_bf16_to_f32(L.ptr(self.mu), self.n_vi, L.ptr(out), sp))
+        L.check(lib.mfvi_bf16_to_f32(L.ptr(self.rho), self.n_vi, L.ptr(out[self.n_vi:]), sp))
+        return out[:self.n_vi], out[self.n_vi:], self.bn
 
     def step(self):
         """One ELBO iteration: K forwards + NLL + backward + (all-reduce), then KL + its gradient + Adam in one fused launch
@@ -156,6 +186,11 @@ class ElboEngine:
         lib, sp = L.lib(), L.stream_ptr()
         self.grad_only(self.t, with_kl=False)
         self.t += 1
+        if self.param_dtype == "bf16":
+            L.check(lib.mfvi_elbo_update_bf16(L.ptr(self.mu), L.ptr(self.rho), L.ptr(self.bn), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi,
+                                              self.n_bn, 0.0, self.prior_sigma, self.temp, self.lr, 0.9, 0.999, 1e-8, self.t, self.seed,
+                                              L.ptr(self.acc[1:]), L.ptr(self.upd_scratch), sp))
+            return
         if self.task == TASK_CT:
             # `if not torch.isnan(loss): optimizer.step()` (bayesian_optimization.py:581-582) decided on the device: no host sync
             L.check(lib.mfvi_elbo_update_guarded(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi, self.n_bn, 0.0,

@@ -65,22 +65,27 @@ class Program:
         p = ksize // 2
         return (t["H"] + 2 * p - ksize) // stride + 1, (t["W"] + 2 * p - ksize) // stride + 1
 
-    def compile(self, input_id, output_id, max_samples):
-        return Plan(self, input_id, output_id, max_samples)
+    def compile(self, input_id, output_id, max_samples, param_dtype="f32"):
+        return Plan(self, input_id, output_id, max_samples, param_dtype)
 
 
 class Plan:
     """Compiled program + workspace on the current CUDA device."""
 
-    def __init__(self, prog, input_id, output_id, max_samples):
+    def __init__(self, prog, input_id, output_id, max_samples, param_dtype="f32"):
         import torch
         self.prog, self.input_id, self.output_id, self.max_samples = prog, input_id, output_id, max_samples
+        if param_dtype not in ("f32", "bf16"):
+            raise ValueError("param_dtype %r: 'f32' or 'bf16'" % (param_dtype,))
+        self.param_dtype = param_dtype
         td = (L.TensorDesc * len(prog.tensors))(*[L.TensorDesc(**t) for t in prog.tensors])
         od = (L.OpDesc * len(prog.ops))(*[L.OpDesc(**o) for o in prog.ops])
         h = C.c_void_p()
         L.check(L.lib().mfvi_plan_create(td, len(prog.tensors), od, len(prog.ops), input_id, output_id, prog.n_vi, prog.n_bn,
                                          max_samples, C.byref(h)))
         self.handle = h
+        if param_dtype == "bf16":       # mu / rho handed to forward / backward are torch.bfloat16 tensors
+            L.check(L.lib().mfvi_plan_set_param_dtype(h, L.PARAM_BF16))
         self.workspace_bytes = L.lib().mfvi_plan_workspace_bytes(h)
         self.workspace = torch.empty(max(self.workspace_bytes, 16), dtype=torch.uint8, device="cuda")
         self.in_shape = tuple(prog.tensors[input_id][k] for k in ("C", "H", "W"))
@@ -99,11 +104,19 @@ class Plan:
         if out is None:
             out = torch.empty((n_samples,) + self.out_shape, dtype=torch.float32, device="cuda")
         assert z.is_contiguous() and z.dtype == torch.float32 and z.numel() == self.in_shape[0] * self.in_shape[1] * self.in_shape[2]
+        self._check_params(mu, rho)
         L.check(L.lib().mfvi_forward(self.handle, L.ptr(mu), L.ptr(rho), L.ptr(bn), L.ptr(z), seed, step, k0, n_samples,
                                      int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(out), L.stream_ptr()))
         return out
 
+    def _check_params(self, mu, rho):
+        import torch
+        want = torch.bfloat16 if self.param_dtype == "bf16" else torch.float32
+        if mu.dtype != want or rho.dtype != want:
+            raise TypeError("this plan takes %s mu / rho, got %s / %s" % (want, mu.dtype, rho.dtype))
+
     def backward(self, mu, rho, bn, z, seed, step, k0, n_samples, dout, dmu, drho, dbn, sample_weights=True, dz=None):
+        self._check_params(mu, rho)
         assert dout.is_contiguous() and dout.numel() == n_samples * self.out_shape[0] * self.out_shape[1] * self.out_shape[2]
         L.check(L.lib().mfvi_backward(self.handle, L.ptr(mu), L.ptr(rho), L.ptr(bn), L.ptr(z), seed, step, k0, n_samples,
                                       int(bool(sample_weights)), L.ptr(self.workspace), L.ptr(dout), L.ptr(dmu), L.ptr(drho),

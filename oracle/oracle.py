@@ -499,3 +499,9 @@ def bf16_bits(x):
 
 def bf16_from_bits(b):
     return (np.ascontiguousarray(b, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def adam_bf16_sr(p_bits, g, m, v, lr, t, seed, stream):
+    """In place: Adam in float32 + stochastic rounding to bf16 (the build's update rule for bf16 mu / rho); p_bits uint16, g / m / v float32."""
+    assert p_bits.dtype == np.uint16 and p_bits.flags.c_contiguous
+    lib().oracle_adam_bf16_sr(_p(p_bits), _p(g), _p(m), _p(v), C.c_long(p_bits.size), C.c_float(lr), C.c_int(t), C.c_uint64(seed), C.c_uint32(stream))

@@ -133,8 +133,8 @@ def test_cfg4_ct_256_radon_adjoint_and_descent(M):
 
 def test_cfg5_den_512_k64_chunked(M):
     """configs[4]: one 512x512 denoising fit per GPU with K = 64 MC samples, evaluated as 4 launches of 16 (one workspace): the
-    gradient equals the one of 8 launches of 8 (eps keyed by the global sample index), and the fit descends.  (fp32 parameters:
-    bf16 storage of mu / rho is not built)"""
+    gradient equals the one of 8 launches of 8 (eps keyed by the global sample index), and the fit descends.  (float32 parameters
+    here; the same configuration with bf16 mu / rho, as configs[4] states it: tests/test_gpu_bf16.py::test_cfg5_den_512_k64_bf16.)"""
     S2, K2 = 512, 64
     tgt = torch.from_numpy(O.noisy(O.phantom(S2, S2, 1), 0.1, 1))
     def eng(spl):
