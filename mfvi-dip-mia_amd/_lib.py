@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmfvi_hip.so")
+LIB_PATH = os.environ.get("MFVI_LIB_PATH") or os.path.join(HERE, "libmfvi_hip.so")      # MFVI_LIB_PATH: an experimental build (A/B timing)
 
 OP_CONV, OP_CONCAT_UP = 1, 2
 DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD, DOMAIN_DROPOUT, DOMAIN_ROUND = 0, 1, 2, 3, 4, 5, 6

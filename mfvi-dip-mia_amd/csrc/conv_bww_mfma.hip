@@ -181,12 +181,21 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         };
         int ks = wv;
         if (ks >= NKS) return;
+#ifndef MFVI_FENCE
+#define MFVI_FENCE 1
+#endif
+        // scheduling fences: keep "request the next k-step's operands, then issue this k-step's MFMAs" as written (the machine scheduler
+        // otherwise sinks the ds_reads next to their uses and the wave waits on LDS with an idle matrix pipe)
         load(ks, a[0], bq[0]);
         for (; ks + NW < NKS; ks += 2 * NW) {
             load(ks + NW, a[1], bq[1]);
+            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
             fma_all(a[0], bq[0]);
+            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
             if (ks + 2 * NW < NKS) load(ks + 2 * NW, a[0], bq[0]);
+            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
             fma_all(a[1], bq[1]);
+            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
         }
         if (ks < NKS) fma_all(a[0], bq[0]);
     };

@@ -97,10 +97,18 @@ struct MfmaArgs {
 // (columns px0 + 2*l15 + parity) of one row, and issues the 1 / 2 / 2 / 4 of the 9 taps its (row parity, column parity) class can see,
 // reading the UN-stuffed dy window ((TH/2 + 2) rows x 24 columns) — a quarter of the MFMAs and of the staged window of the
 // zero-stuffed formulation, same per-element accumulation order (the skipped products are exact zeros).
-template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false, bool PH = false>
+// FF (MODE 1, 3x3 stride-1 layers whose input tensor has no other consumer): the gradient is formed on the UN-padded input domain and the
+// fold runs in the epilogue.  The adjoint of ReflectionPad2d(1) sends padded row 0 to input row 1 and padded row H+1 to row H-2 (columns
+// alike); in the tap sum  dx[i][j] = sum_{ky,kx} w'[ky][kx] * dy[i-1+ky][j-1+kx]  that is
+//     row i == 1:    B(ky=2, kx) += B(ky=0, kx)         row i == H-2:  B(ky=0, kx) += B(ky=2, kx)
+//     col j == 1:    B(ky, kx=2) += B(ky, kx=0)         col j == W-2:  B(ky, kx=0) += B(ky, kx=2)       (corners: both, 4 terms)
+// on the pixel operand B of the lanes concerned — a few extra LDS reads in the border tiles, no extra MFMA, and neither the (H+2)x(W+2)
+// padded-gradient scratch (written and re-read: 2 x 100 MB per pass of up_9) nor the finalize_dx launch exist any more.
+template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false, bool PH = false, bool FF = false>
 __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
 {
     static_assert(!PH || (MODE == 1 && KS == 3 && !FLAT && !BIGC), "phase decomposition: 3x3 backward-data on rectangular tiles");
+    static_assert(!FF || (MODE == 1 && KS == 3 && STRIDE == 1 && !PH && !BIGC), "fused fold: 3x3 stride-1 backward-data");
     using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     // other half of a double buffer.  One barrier per chunk; VALU/VMEM work hides under the matrix pipe.
     extern __shared__ __align__(16) float s_w[];          // WS: [KK][REDP][CTP]; else 2 x [KK][CC][CTP]
     __shared__ __align__(16) float s_x[2][Cfg::X_FLOATS];
-    __shared__ ChanFwd s_ch[(MODE == 0 || KS == 1) ? MFVI_MAX_C : 1];
+    __shared__ ChanFwd s_ch[(MODE == 0 || KS == 1 || FF) ? MFVI_MAX_C : 1];
     __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
     __shared__ double s_red[4][CT][2];
@@ -147,9 +155,9 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         }
     } else {
         for (int c = tid; c < g.Cout; c += 512) s_chb[c] = chan_bwd(A.gin, k, c);
-        if constexpr (KS == 1) { if (A.fga) for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c); }
+        if constexpr (KS == 1 || FF) { if (A.fga) for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c); }
     }
-    const bool fuse = MODE == 1 && KS == 1 && A.fga != nullptr;
+    const bool fuse = MODE == 1 && (KS == 1 || FF) && A.fga != nullptr;
     const bool fuse_sums = fuse && A.fbsums != nullptr;
 
     // Copy the weight slab of reduction channels [c0, c0+cc) of this sample into wdst[tap][kbase + kk][m] with `nthr` threads.
@@ -218,8 +226,8 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         int goff[FLAT ? NPX : 1];                                           // global offset of position lane + 64*j; -1 = stage a zero
         auto set_tile_s = [&](int tile) {
             const int px0 = 0, py0 = tile * A.rt;
-            const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1);
-            const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (KS - 1);
+            const int sy0 = MODE == 0 ? py0 * STRIDE - P : py0 - (FF ? P : KS - 1);      // FF: un-padded output domain, halo P on each side
+            const int sx0 = MODE == 0 ? px0 * STRIDE - P : px0 - (FF ? P : KS - 1);
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
                 const int p = min(lane + 64 * j, nwin - 1), iy = p / A.wpitch, ix = p - iy * A.wpitch;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         float4 xv[FLAT ? 1 : CPW][FLAT ? 1 : NV], yv[(!FLAT && MODE == 1) ? CPW : 1][(!FLAT && MODE == 1) ? NV : 1];
         auto set_tile_v = [&](int tile) {
             const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
-            const int sy0 = PH ? py0 / 2 - 1 : (MODE == 0 ? py0 * STRIDE - P : py0 - (KS - 1));
+            const int sy0 = PH ? py0 / 2 - 1 : (MODE == 0 ? py0 * STRIDE - P : py0 - (FF ? P : KS - 1));
             const int ax0 = (PH ? px0 / 2 : (MODE == 0 ? px0 * STRIDE : px0)) - Cfg::HALO4;            // aligned first column of the LDS row
             const bool stuffed = !PH && MODE == 1 && g.stride == 2;
 #pragma unroll
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             } else {
                 const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
                 if constexpr (PH) boff[f] = l4 * PLANE + (wv * (TH / 8)) * 24 + l15 + 3;      // window row (R + r + ky)/2, R = wv*TH/4 even; column l15 + (parity + kx)/2 + 3
-                else boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? (MODE == 0 ? 3 : 2) : 0);
+                else boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? ((MODE == 0 || FF) ? 3 : 2) : 0);
             }
         }
         const int aoff = l4 * CTP + l15;
@@ -409,6 +417,11 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         for (int it = 0; it < n_iters; ++it) {
             const int tile = tile_begin + it / n_chunks, ci = it % n_chunks, c0 = ci * CC;
             const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
+            // FF: origin of the tile in the un-padded input domain and whether it holds a reflected row (1, H-2) / column (1, W-2)
+            const int tpx0 = FLAT ? 0 : (tile % A.tiles_x) * TW, tpy0 = FLAT ? tile * A.rt : (tile / A.tiles_x) * TH;
+            const int trows = FLAT ? A.rt : TH;
+            const bool spr = FF && ((tpy0 <= 1 && 1 < tpy0 + trows) || (tpy0 <= g.H - 2 && g.H - 2 < tpy0 + trows));
+            const bool spc = FF && (FLAT || tpx0 == 0 || (tpx0 <= g.W - 2 && g.W - 2 < tpx0 + TW));
             if (ci == 0) {
 #pragma unroll
                 for (int a = 0; a < MF; ++a)
@@ -419,8 +432,9 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             //      so the LDS reads of step q+1 are in flight while the matrix core runs step q ----
             const float* __restrict__ sx = s_x[it & 1];
             const float* __restrict__ wq = (WS ? s_w + c0 * CTP : s_w + (it & 1) * WCHUNK) + aoff;
-            auto run = [&](auto steps_c, int sbase) {          // STEPS 4-channel steps of the chunk, starting at step sbase
+            auto run_sp = [&](auto steps_c, auto spr_c, auto spc_c, int sbase) {          // STEPS 4-channel steps of the chunk, starting at step sbase
                 constexpr int STEPS = decltype(steps_c)::value, NQ = KK * STEPS;
+                constexpr bool SPR = decltype(spr_c)::value, SPC = decltype(spc_c)::value;
 #ifndef MFMA_STAGES
 #define MFMA_STAGES 2
 #endif
@@ -437,13 +451,38 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                                 bb[f] = sx[(sbase + st_) * 4 * PLANE + boff[f] + (((f >> 1) + ky) >> 1) * 24 + (((f & 1) + kx) >> 1)];
                         } else
                         bb[f] = FLAT ? sx[(sbase + st_) * 4 * PLANE + boffk[f][ky] + kx] : sx[(sbase + st_) * 4 * PLANE + boff[f] + ky * PITCH + kx];
+                        if constexpr (FF && (SPR || SPC)) {
+                            // adjoint of the reflection padding on the B operand (see the kernel's header); flags are 1.0 on the lanes concerned
+                            auto rd = [&](int ky2, int kx2) -> float {
+                                if constexpr (FLAT) return sx[(sbase + st_) * 4 * PLANE + boffk[f][ky2] + kx2];
+                                else return sx[(sbase + st_) * 4 * PLANE + boff[f] + ky2 * PITCH + kx2];
+                            };
+                            int rowf, colf;
+                            if constexpr (FLAT) { rowf = tpy0 + (frc[f] >> 16); colf = frc[f] & 0xffff; }
+                            else { rowf = tpy0 + wv * (TH / 4) + (f >> 1); colf = tpx0 + (f & 1) * 16 + l15; }
+                            const float fr = (SPR && ky != 1 && rowf == (ky == 2 ? 1 : g.H - 2)) ? 1.f : 0.f;
+                            const float fc = (SPC && kx != 1 && colf == (kx == 2 ? 1 : g.W - 2)) ? 1.f : 0.f;
+                            float e = 0.f;
+                            if constexpr (SPR) { if (ky != 1) e = __builtin_fmaf(fr, rd(2 - ky, kx), e); }
+                            if constexpr (SPC) { if (kx != 1) e = __builtin_fmaf(fc, rd(ky, 2 - kx), e); }
+                            if constexpr (SPR && SPC) { if (ky != 1 && kx != 1) e = __builtin_fmaf(fr * fc, rd(2 - ky, 2 - kx), e); }
+                            bb[f] += e;
+                        }
                     }
                 };
+#ifndef MFVI_FENCE
+#define MFVI_FENCE 0
+#endif
+                // MFVI_FENCE=1: scheduling fences keep the software pipeline as written — operands of k-step q + 1 requested, THEN the MFMAs of
+                // k-step q.  Without them the machine scheduler pulls each ds_read down next to its first use (fewer live registers) and a wave
+                // sits in `s_waitcnt lgkmcnt(0)` a dozen times per stage.  Measured on MI355X (profiles/r02_fence_ab.txt): no difference, the
+                // other two consumer waves of the SIMD fill those gaps — kept as an A/B switch.
 #pragma unroll
                 for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if (q + SG - 1 < NQ) load(q + SG - 1, a[(q + SG - 1) % SG], b[(q + SG - 1) % SG]);
+                    if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
                     const int tapq = q / STEPS, kyq = tapq / KS, kxq = tapq % KS;
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
@@ -451,7 +490,17 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                         for (int f = 0; f < NF; ++f)
                             if (!PH || ((((f >> 1) + kyq) & 1) == 0 && (((f & 1) + kxq) & 1) == 0))
                                 acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q % SG][i], b[q % SG][f], acc[i][f], 0, 0, 0);
+                    if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            auto run = [&](auto steps_c, int sbase) {          // border tiles take the variant with the reflected rows / columns they hold
+                constexpr std::false_type no{}; constexpr std::true_type yes{};
+                if constexpr (FF) {
+                    if (spr && spc) run_sp(steps_c, yes, yes, sbase);
+                    else if (spr) run_sp(steps_c, yes, no, sbase);
+                    else if (spc) run_sp(steps_c, no, yes, sbase);
+                    else run_sp(steps_c, no, no, sbase);
+                } else run_sp(steps_c, no, no, sbase);
             };
             if constexpr (CC == 8) {
                 if (cc4 == 8) run(std::integral_constant<int, 2>{}, 0); else run(std::integral_constant<int, 1>{}, 0);
@@ -524,7 +573,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                         done = true;
                     }
                     if (MODE == 1) {
-                        const int Hp = g.H + 2 * P, Wp = g.W + 2 * P, HWp = Hp * Wp;
+                        const int Hp = FF ? g.H : g.H + 2 * P, Wp = FF ? g.W : g.W + 2 * P, HWp = Hp * Wp;
                         float* __restrict__ o = fuse ? A.fga + (long long)k * A.fga_sstride + (long long)m0 * HWp
                                                      : A.dxp + (long long)k * A.dxp_sstride + (long long)m0 * HWp;
                         const float* __restrict__ xraw = fuse_sums ? A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HWp : nullptr;
@@ -544,8 +593,8 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #pragma unroll
                                 for (int u = 0; u < 2; ++u) {
                                     const int ch = ech + 8 * u, pc = px0 + 4 * ev4;
-                                    if (KS == 1 && fuse) {
-                                        // 1x1, single consumer: no padding ring, (pr, pc) IS the input pixel -> LeakyReLU' and the BN-backward sums here
+                                    if ((KS == 1 || FF) && fuse) {
+                                        // 1x1 / un-padded 3x3 domain, single consumer: (pr, pc) IS the input pixel -> LeakyReLU' and the BN-backward sums here
                                         if (i * 16 + ch < mt && pr < Hp && pc < Wp) {
                                             const int ofs = (i * 16 + ch) * HWp + pr * Wp + pc;           // Wp == W, a multiple of 4: aligned float4
                                             const float4 v = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
@@ -628,6 +677,53 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                                 if (l15 == 0) { s_red[wv][i * 16 + l4 * 4 + r][0] += (double)a; s_red[wv][i * 16 + l4 * 4 + r][1] += (double)b; }
                             }
                     }
+                } else if constexpr (FF) {
+                    // FLAT tiles of the fused fold: per-element LeakyReLU' and BN-backward partial sums, gradient straight to ga
+                    const int Hp = g.H, Wp = g.W, HWp = Hp * Wp;
+                    float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * HWp;
+                    const float* __restrict__ xraw = fuse_sums ? A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HWp : nullptr;
+                    const int rowbase = l4 * 4 * HWp;
+                    float fs[MF][4], fq[MF][4];
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { fs[i][r] = 0.f; fq[i][r] = 0.f; }
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const int pr = py0 + (frc[f] >> 16), pc = frc[f] & 0xffff;
+                            if (frc[f] >= 0 && pr < Hp && pc < Wp) {
+                                const int pofs = rowbase + pr * Wp + pc;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int ml = i * 16 + l4 * 4 + r;
+                                    if (ml < mt) {
+                                        const int ofs = (i * 16 + r) * HWp + pofs;
+                                        float d = acc[i][f][r];
+                                        if (fuse_sums) {
+                                            const float y = xraw[ofs];
+                                            const ChanFwd cf = s_ch[m0 + ml];
+                                            const float vv = __builtin_fmaf(y - cf.mean, cf.scale, cf.beta);
+                                            if (A.xin.act && !(vv > 0.f)) d *= A.xin.slope;
+                                            fs[i][r] += d; fq[i][r] = __builtin_fmaf(d, (y - cf.mean) * cf.rstd, fq[i][r]);
+                                        }
+                                        o[ofs] = d;
+                                    }
+                                }
+                            }
+                        }
+                    if (fuse_sums) {
+#pragma unroll
+                        for (int i = 0; i < MF; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float a = fs[i][r], b = fq[i][r];
+#pragma unroll
+                                for (int o2 = 8; o2 > 0; o2 >>= 1) { a += __shfl_xor(a, o2, 64); b += __shfl_xor(b, o2, 64); }
+                                if (l15 == 0) { s_red[wv][i * 16 + l4 * 4 + r][0] += (double)a; s_red[wv][i * 16 + l4 * 4 + r][1] += (double)b; }
+                            }
+                    }
                 } else {
                     const int Hp = g.H + 2 * P, Wp = g.W + 2 * P, HWp = Hp * Wp;
                     float* __restrict__ o = A.dxp + (long long)k * A.dxp_sstride + (long long)m0 * HWp;
@@ -685,7 +781,9 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
                    long long dxp_sstride, int n_samples, hipStream_t st, FoldFuse fuse = FoldFuse{})
 {
     const int P = g.ks / 2, KK = KS * KS;
-    const int OH = MODE == 0 ? g.Ho : g.H + 2 * P, OW = MODE == 0 ? g.Wo : g.W + 2 * P;    // output pixel domain
+    constexpr bool CAN_FF = MODE == 1 && KS == 3 && STRIDE == 1;
+    const bool ff = CAN_FF && g.stride == 1 && fuse.ga != nullptr;                           // 3x3 stride-1 backward-data with the fold in its epilogue
+    const int OH = MODE == 0 ? g.Ho : (ff ? g.H : g.H + 2 * P), OW = MODE == 0 ? g.Wo : (ff ? g.W : g.W + 2 * P);    // output pixel domain
     const int MOUT = MODE == 0 ? g.Cout : g.Cin, RED = MODE == 0 ? g.Cin : g.Cout;
     const int RED4 = (RED + 3) & ~3;
     MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, fuse.ga, fuse.ga_sstride, fuse.bsums, 0, 0, 1};
@@ -707,6 +805,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         using Cfg = MCfg<KS, STRIDE, MF_, TH_>;                                                                            \
         A.tiles_x = (OW + 31) / 32;                                                                                        \
         A.n_tiles = A.tiles_x * ((OH + TH_ - 1) / TH_);                                                                    \
+        if ((FL_) && ff && (OW & 15)) return -3;      /* fused fold on FLAT tiles: a 16-pixel fragment must not straddle two rows */ \
         if (FL_) {                                                                                                         \
             A.ow = OW; A.wpitch = (OW - 1) * STRIDE + KS;                                                                  \
             int rt = (TH_ * 32) / OW;                                                                                      \
@@ -734,7 +833,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (lds_big + ws_bytes > 150 * 1024) big = false;                                                              \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
         } else {                                                                                                           \
@@ -743,7 +843,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (big) ck_bytes = ck_big;                                                                                    \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
-            if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
         }                                                                                                                  \
@@ -814,9 +915,11 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
     const int wa = g.stride == 2 ? 1 : 3;
     if ((g.Wo & wa) || g.Wo < (wa + 1) || (gy.gstride & wa) || ((uintptr_t)gy.ga & 15) || (gy.y && ((gy.ystride & wa) || ((uintptr_t)gy.y & 15)))) return -2;
     TView none{}; OutDesc od{};
-    if (fuse) {       // 1x1 layer, the fold runs in the epilogue: aligned float4 rows of the input tensor and of its gradient
-        if (g.ks != 1 || !fuse->ga || (g.W & 3) || (fuse->ga_sstride & 3) || ((uintptr_t)fuse->ga & 15)) return -2;
+    if (fuse) {       // the fold runs in the epilogue: aligned float4 rows of the input tensor and of its gradient
+        if (!(g.ks == 1 || (g.ks == 3 && g.stride == 1)) || !fuse->ga || (g.W & 3) || (fuse->ga_sstride & 3) || ((uintptr_t)fuse->ga & 15)) return -2;
         if (fuse->bsums && ((fuse->x.sstride & 3) || ((uintptr_t)fuse->x.data & 15))) return -2;
+        if (g.ks == 3 && (g.H < 4 || g.W < 4)) return -2;      // rows 1 and H-2 (columns 1 and W-2) must be distinct, interior lines
+        if (g.ks == 3) return launch_variant<3, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
         return launch_variant<1, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
     }
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);

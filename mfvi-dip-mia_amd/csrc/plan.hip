@@ -314,6 +314,13 @@ bool fold_fusion_on()
     return on;
 }
 
+// MFVI_FOLD_FUSION3=0: 3x3 stride-1 backward-data keeps the padded-gradient scratch + finalize_dx (A/B and parity cross-checks)
+bool fold_fusion3_on()
+{
+    static const bool on = [] { const char* e = getenv("MFVI_FOLD_FUSION3"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool grad_from_slab()
 {
     static const bool on = [] { const char* e = getenv("MFVI_GRAD_FROM_SLAB"); return e && e[0] == '1'; }();
@@ -535,8 +542,9 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                 const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
                 const TensorInfo& x = plan->t[o.d.in0];
                 bool folded = false;
-                if (o.g.ks == 1 && x.consumers.size() == 1 && use_mfma() && fold_fusion_on()) {
-                    // 1x1 layer feeding nothing else: backward-data with the fold in its epilogue (no scratch round trip, no finalize_dx launch)
+                if ((o.g.ks == 1 || (o.g.ks == 3 && o.g.stride == 1 && fold_fusion3_on())) && x.consumers.size() == 1 && use_mfma() && fold_fusion_on()) {
+                    // the conv's input feeds nothing else: backward-data with the fold in its epilogue (no scratch round trip, no finalize_dx
+                    // launch); 3x3 stride-1 layers compute on the un-padded domain with the reflection adjoint on the pixel operand
                     FoldFuse ff; ff.x = xin; ff.ga = (o.d.in0 == plan->input) ? dz : c.farena() + x.ga_off; ff.ga_sstride = x.numel;
                     ff.bsums = x.d.has_bn ? c.bsums() + x.stats_off : nullptr;
                     ProfScope ps(plan, i, PASS_BWD_DATA, st);
@@ -715,7 +723,17 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
             int strips_used = 0;
             auto launch = [&]() {
                 if (which == 0) return launch_conv_fwd_mfma(xin, o.g, c.wsamp(), plan->n_vi, od, n_samples, st);
-                if (which == 1) return launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, c.farena() + o.scratch_off, per, n_samples, st);
+                if (which == 1) {
+                    const TensorInfo& x = plan->t[o.d.in0];
+                    if ((o.g.ks == 1 || (o.g.ks == 3 && o.g.stride == 1 && fold_fusion3_on())) && x.consumers.size() == 1 && fold_fusion_on() && o.d.in0 != plan->input) {
+                        // the fused-fold variant mfvi_backward will launch (it accumulates into the BN-backward sums: contents undefined afterwards)
+                        FoldFuse ff; ff.x = xin; ff.ga = c.farena() + x.ga_off; ff.ga_sstride = x.numel;
+                        ff.bsums = x.d.has_bn ? c.bsums() + x.stats_off : nullptr;
+                        const int r2 = launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, nullptr, 0, n_samples, st, &ff);
+                        if (r2 != -2) return r2;
+                    }
+                    return launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, c.farena() + o.scratch_off, per, n_samples, st);
+                }
                 return launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips_used, n_samples, st);
             };
             // candidate tilings: fwd / bwd-data (mf, th, T) = fragments x tile rows x tiles per block;
