@@ -600,7 +600,11 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                                             const float4 v = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
                                             float dd[4] = {v.x, v.y, v.z, v.w};
                                             if (fuse_sums) {
+#ifdef MFVI_DBG_NOXLOAD      /* timing experiment only (wrong results): how much of the epilogue is the latency of this load */
+                                                const float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
                                                 const float4 y4 = *reinterpret_cast<const float4*>(xraw + ofs);
+#endif
                                                 const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
                                                 const ChanFwd cf = s_ch[m0 + i * 16 + ch];
 #pragma unroll

@@ -176,14 +176,16 @@ class _BookInp:
         return mt[:, 0], mt[:, 0], psnrs, mt[:, 4:7]                          # the reference computes both MSEs against img_torch (:3051-3052)
 
 
-def _make_engine(method, H, W, task, K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, **kw):
+def _make_engine(method, H, W, task, K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, param_dtype="f32", **kw):
+    if param_dtype != "f32":
+        kw["param_dtype"] = param_dtype             # bf16 mu / rho (BASELINE configs[4]); the MFVI engines only
     if method == "mfvi":
         return ElboEngine(H, W, task=task, K=K, input_depth=input_depth, temp=temp, sigma=sigma, lr=lr, seed=seed, net_kwargs=net_kwargs, **kw)
     return SiblingEngine(H, W, method=method, task=task, K=K, input_depth=input_depth, lr=lr, seed=seed, net_kwargs=net_kwargs, **sib, **kw)
 
 
 def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, seed, show_every, plot, save, save_path, K, factor=4,
-         theta_step=4.0, verbose=False, net_kwargs=None, method="mfvi", weight_decay=0.0, dropout_p=0.3, gamma=0.996, **unused):
+         theta_step=4.0, verbose=False, net_kwargs=None, method="mfvi", weight_decay=0.0, dropout_p=0.3, gamma=0.996, param_dtype="f32", **unused):
     import torch
     sib = dict(weight_decay=weight_decay, dropout_p=dropout_p, gamma=gamma)
     timestamp = str(time.time())
@@ -206,11 +208,11 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
         rng = np.random.default_rng(seed + 1)
         noisy = np.clip(img_np + rng.normal(scale=p_sigma, size=img_np.shape), 0, 1).astype(np.float32)      # denoising_utils.py:11
         target = noisy
-        eng = _make_engine(method, H, W, "den", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib)
+        eng = _make_engine(method, H, W, "den", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, param_dtype=param_dtype)
     elif task == "sr":
         target = np.ascontiguousarray(img_np[::factor, ::factor])    # nearest /factor decimation (:2095-2099)
         noisy = None
-        eng = _make_engine(method, H, W, "sr", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, sr_factor=factor)
+        eng = _make_engine(method, H, W, "sr", K, input_depth, temp, sigma, lr, seed, net_kwargs, sib, sr_factor=factor, param_dtype=param_dtype)
         extra["img_lr"] = target
     else:
         theta = np.arange(0, 180.0, theta_step, dtype=np.float32)     # :545
@@ -383,19 +385,26 @@ run_inp_sgld = _sibling("inp", "sgld", dict(input_depth=32, lr=2e-3, gamma=0.996
 BO_KEYS = {"mfvi": ("temp", "sigma"), "mcd": ("dropout_p", "weight_decay"), "sgld": ("gamma", "weight_decay"), "dip": ()}
 
 
-def load_config(path, bayes="mfvi"):
+def load_config(path, bayes="mfvi", with_devices=False):
     """The reference's JSON schema {bo_params:{<name>:{candidates}, ...}, run_params:{...}} (bayesian_optimization.py:3901-3909 reads it
-    through pandas; plain json is equivalent).  Returns ([candidate dicts], run_params)."""
+    through pandas; plain json is equivalent).  Returns ([candidate dicts], run_params[, devices]); `devices` is run_params['devices']
+    of the reference's configs (eval_result.py:21-22), e.g. ["cuda:0", ..., "cuda:7"]."""
     cfg = json.load(open(path))
     rp = dict(cfg["run_params"])
-    for k in ("bo_results_path", "devices"):                          # eval_result.py:21-22
-        rp.pop(k, None)
+    devices = rp.pop("devices", None)
+    rp.pop("bo_results_path", None)
     keys = BO_KEYS[bayes]
     if not keys:
-        return [dict()], rp
-    a, b = keys
-    cands = [{a: x, b: y} for x in cfg["bo_params"][a]["candidates"] for y in cfg["bo_params"][b]["candidates"]]
-    return cands, rp
+        cands = [dict()]
+    else:
+        a, b = keys
+        cands = [{a: x, b: y} for x in cfg["bo_params"][a]["candidates"] for y in cfg["bo_params"][b]["candidates"]]
+    return (cands, rp, devices) if with_devices else (cands, rp)
+
+
+def fit_job(fn_name, **kw):
+    """One independent fit in a worker process of the fan-out: run_<task>_<method>(**kw) -> PSNR (the reference's return value)."""
+    return globals()[fn_name](**kw)["psnr"]
 
 
 def main(argv=None):
@@ -403,16 +412,19 @@ def main(argv=None):
     ap.add_argument("--task", default="denoising", choices=["denoising", "super-resolution", "ct", "inpainting"])
     ap.add_argument("--bayes", default="mfvi", choices=["mfvi", "dip", "mcd", "sgld"])
     ap.add_argument("--config", required=True)
-    ap.add_argument("--img", default=None); ap.add_argument("--imsize", type=int, default=None)
+    ap.add_argument("--img", default=None, help="one image, or a comma-separated list: every (image, candidate) pair is one independent fit")
+    ap.add_argument("--imsize", type=int, default=None)
     ap.add_argument("--k", type=int, default=1); ap.add_argument("--num-iter", type=int, default=None); ap.add_argument("--save-path", default=None)
+    ap.add_argument("--devices", default=None, help="comma-separated devices (cuda:0,cuda:1,...): the independent fits are dealt round-robin to one "
+                                                    "fresh worker process per device (default: the config's run_params.devices; absent: this process)")
+    ap.add_argument("--param-dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args(argv)
-    cands, rp = load_config(a.config, a.bayes)
+    cands, rp, cfg_devices = load_config(a.config, a.bayes, with_devices=True)
     short = {"denoising": "den", "super-resolution": "sr", "ct": "ct", "inpainting": "inp"}[a.task]
-    fn = globals().get("run_%s_%s" % (short, a.bayes))                # f(): bayesian_optimization.py:3709-3724
+    fn_name = "run_%s_%s" % (short, a.bayes)
+    fn = globals().get(fn_name)                # f(): bayesian_optimization.py:3709-3724
     if fn is None:
         raise NotImplementedError("run_%s_%s is not built" % (short, a.bayes))
-    if a.img is not None:
-        rp["img"] = a.img
     if a.imsize:
         rp["imsize"] = (a.imsize, a.imsize)
     if a.num_iter is not None:
@@ -420,9 +432,28 @@ def main(argv=None):
     if a.save_path:
         rp["save_path"] = a.save_path
     rp["plot"] = False
-    for cand in cands:
-        r = fn(K=a.k, verbose=True, **cand, **rp)
+    if a.param_dtype != "f32":
+        rp["param_dtype"] = a.param_dtype
+    imgs = a.img.split(",") if a.img else [rp.pop("img", "phantom")]
+    rp.pop("img", None)
+    jobs = [dict(cand, img=im) for im in imgs for cand in cands]
+    devices = a.devices.split(",") if a.devices else cfg_devices
+    if devices:
+        # independent fits over the node's GPUs (bayesian_optimization.py:3760-3781, eval_result.py:27-53): no per-step communication,
+        # one final gather of (candidate, psnr), NaNs dropped
+        from .fanout import run_jobs, print_table
+        results, dropped = run_jobs(jobs, devices, "mfvi_dip_mia_amd.runner:fit_job", dict(rp, fn_name=fn_name, K=a.k))
+        print_table(results, list(BO_KEYS[a.bayes]))
+        for i, job, why in dropped:
+            print("dropped fit %d %s: %s" % (i, {k: v for k, v in job.items() if k != "img"}, why))
+        return results
+    out = []
+    for job in jobs:
+        r = fn(K=a.k, verbose=True, **job, **rp)
+        cand = {k: v for k, v in job.items() if k != "img"}
         print("%s -> PSNR %.3f dB in %.1f s (%s)" % (" ".join("%s %.3e" % kv for kv in cand.items()) or "dip", r["psnr"], r["seconds"], r["run_dir"]))
+        out.append(r)
+    return out
 
 
 if __name__ == "__main__":

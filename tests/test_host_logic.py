@@ -150,3 +150,40 @@ def test_inpainting_skip_builder_matches_reference_state_dict_keys(golden_dir):
         else:
             mine.append("net." + k)
     assert mine == ref
+
+
+def test_independent_fit_fanout_with_stub_worker():
+    """mfvi_dip_mia_amd.fanout (the reference's candidate fan-out, bayesian_optimization.py:3760-3781 / eval_result.py:27-53): jobs dealt
+    round-robin over the devices, ONE fresh (spawned) process per device, (candidate, psnr) gathered through a queue, NaN and crashed
+    fits dropped, order restored."""
+    from mfvi_dip_mia_amd import fanout
+    assert fanout.assign(7, ["a", "b", "c"]) == {"a": [0, 3, 6], "b": [1, 4], "c": [2, 5]}
+    cands = [dict(temp=float(t), sigma=0.5) for t in range(1, 8)]
+    jobs = [dict(c, img=im) for im in ("a", "b") for c in cands]          # 14 independent fits = 2 images x 7 candidates
+    devices = ["cpu:0", "cpu:1", "cpu:2"]
+    results, dropped = fanout.run_jobs(jobs, devices, "fanout_stub:fit", dict(scale=2.0))
+    assert [i for i, _, _ in results] == [i for i in range(14) if jobs[i]["temp"] not in (3.0, 5.0)]
+    for i, job, psnr in results:
+        assert psnr == 2.0 * (10.0 * job["temp"] + 0.5) + (100.0 if job["img"] == "b" else 0.0)
+    assert sorted(i for i, _, _ in dropped) == [2, 4, 9, 11]
+    assert {why for _, job, why in dropped if job["temp"] == 3.0} == {"nan"} and all("boom" in why for _, job, why in dropped if job["temp"] == 5.0)
+    place = fanout.run_jobs.last_placement
+    assert all(place[i][0] == devices[i % 3] for i in range(14))           # zip(jobs, itertools.cycle(devices))
+    pids = {}
+    for i, (dev, pid) in place.items():
+        pids.setdefault(dev, set()).add(pid)
+    assert all(len(v) == 1 for v in pids.values()) and len({next(iter(v)) for v in pids.values()}) == 3     # one process per device
+    assert os.getpid() not in {next(iter(v)) for v in pids.values()}
+
+
+def test_runner_config_devices_and_jobs(tmp_path):
+    """load_config keeps the reference's run_params.devices (eval_result.py:21-22) for the fan-out; the CLI's job list is images x candidates."""
+    import json
+    from mfvi_dip_mia_amd import runner
+    cfg = dict(bo_params=dict(temp=dict(candidates=[1e-6, 2e-6]), sigma=dict(candidates=[1e-5])),
+               run_params=dict(img="phantom", num_iter=3, devices=["cuda:0", "cuda:1"], bo_results_path="x", lr=1e-3))
+    p = tmp_path / "c.json"; p.write_text(json.dumps(cfg))
+    cands, rp, devices = runner.load_config(str(p), "mfvi", with_devices=True)
+    assert devices == ["cuda:0", "cuda:1"] and "devices" not in rp and "bo_results_path" not in rp
+    assert cands == [dict(temp=1e-6, sigma=1e-5), dict(temp=2e-6, sigma=1e-5)]
+    assert runner.load_config(str(p), "mfvi") == (cands, rp)
