@@ -1,0 +1,51 @@
+"""The multi-rank branch of ElboEngine itself: K MC samples sharded over 2 ranks, the single all-reduce of the flat gradient
+buffer with the NLL scalar riding along, losses() under world > 1, identical update on every rank.  The ranks are fresh child processes
+(spawned before any GPU call) that share the one GPU of the test box through the gloo backend; the result must equal the single-rank
+engine with K_total samples (eps is keyed by the GLOBAL sample index)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run_ranks(tmp_path, task, K, steps, world=2):
+    out = str(tmp_path / ("ranks_%s.npz" % task))
+    port = str(29500 + (os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), str(r), str(world), port, out, task, str(K), str(steps)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("task", ["den", "ct"])
+def test_engine_two_ranks_equal_single_rank(tmp_path, task):
+    import mfvi_dip_mia_amd as M
+    from mfvi_dip_mia_amd.engine import ElboEngine
+    from oracle import oracle as O
+    M._lib.lib()
+    K, steps, S = 4, 3, 64
+    z = _run_ranks(tmp_path, task, K, steps)
+    assert z["identical"].all() and int(z["k_local"]) == 2 and int(z["k0"]) == 0
+    eng = ElboEngine(S, S, task=task, K=K, input_depth=8, temp=5.7e-7, sigma=1.5e-5, lr=1e-3, seed=7,
+                     net_kwargs=dict(nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4)), autotune=False)
+    img = O.phantom(S, S, 7)
+    tgt = O.radon_fwd(img, np.arange(0, 180., 4., dtype=np.float32)) if task == "ct" else O.noisy(img, 0.1, 7)
+    eng.set_target(torch.from_numpy(tgt))
+    losses = []
+    for _ in range(steps):
+        eng.step(); losses.append(eng.losses())
+    p1 = eng.params.cpu().numpy()
+    # same samples, same update; the gradient sum is formed in a different order (two partial sums + all-reduce), and the NLL rides the
+    # all-reduce as a float
+    assert np.abs(z["params"] - p1).max() < 2e-5 and np.abs(z["params"] - p1).mean() < 1e-7
+    assert np.allclose(z["losses"], np.array(losses), rtol=2e-6)
+    if task == "ct":
+        assert int(z["t_applied"]) == steps            # the NaN guard read the all-reduced scalar and let every update through
