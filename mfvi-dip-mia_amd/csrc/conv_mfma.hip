@@ -428,6 +428,34 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #pragma unroll
                     for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            // Fused fold on rectangular tiles: the epilogue needs the raw input tensor x (LeakyReLU' and the x-hat of the BN-backward sums)
+            // at the tile's output pixels.  All its float4 are requested together — before the MFMAs of the tile's last chunk when the
+            // registers allow (YPRE_EARLY), else at the head of the epilogue — instead of one dependent global load per 16-channel row pair
+            // between the epilogue's wave barriers (one exposed HBM latency per row pair: 0.199 -> 0.276 ms on up_9).
+#ifndef MFVI_YPRE_EARLY_MAX
+#define MFVI_YPRE_EARLY_MAX 12
+#endif
+            constexpr bool YPRE = MODE == 1 && !FLAT && (KS == 1 || FF);
+            constexpr bool YPRE_EARLY = YPRE && MF * NF <= MFVI_YPRE_EARLY_MAX;
+            float4 ypre[YPRE ? MF : 1][YPRE ? NF / 2 : 1][2];
+            auto load_ypre = [&]() {
+                if constexpr (YPRE) {
+                    const int Hq = FF ? g.H : g.H + 2 * P, Wq = FF ? g.W : g.W + 2 * P, HWq = Hq * Wq;
+                    const float* __restrict__ xq = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HWq;
+                    const int ech_ = lane >> 3, ev4_ = lane & 7;
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int rp = 0; rp < NF / 2; ++rp)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int ch = ech_ + 8 * u, pr = tpy0 + wv * (TH / 4) + rp, pc = tpx0 + 4 * ev4_;
+                                const bool ok = i * 16 + ch < mt && pr < Hq && pc < Wq;
+                                ypre[i][rp][u] = ok ? *reinterpret_cast<const float4*>(xq + (i * 16 + ch) * HWq + pr * Wq + pc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                }
+            };
+            if constexpr (YPRE_EARLY) { if (fuse_sums && ci == n_chunks - 1) load_ypre(); }
             // ---- MFMA: fully unrolled k-steps (tap x 4-channel step), operand fragments double-buffered in registers
             //      so the LDS reads of step q+1 are in flight while the matrix core runs step q ----
             const float* __restrict__ sx = s_x[it & 1];
@@ -580,6 +608,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                         float fsg[MF][2], fsx[MF][2];
 #pragma unroll
                         for (int i = 0; i < MF; ++i) { fsg[i][0] = 0.f; fsg[i][1] = 0.f; fsx[i][0] = 0.f; fsx[i][1] = 0.f; }
+                        if constexpr (YPRE && !YPRE_EARLY) { if (fuse_sums) load_ypre(); }
 #pragma unroll
                         for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -600,11 +629,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                                             const float4 v = *reinterpret_cast<const float4*>(&ep[ch][4 * ev4]);
                                             float dd[4] = {v.x, v.y, v.z, v.w};
                                             if (fuse_sums) {
-#ifdef MFVI_DBG_NOXLOAD      /* timing experiment only (wrong results): how much of the epilogue is the latency of this load */
-                                                const float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
-                                                const float4 y4 = *reinterpret_cast<const float4*>(xraw + ofs);
-#endif
+                                                const float4 y4 = ypre[YPRE ? i : 0][YPRE ? rp : 0][u];
                                                 const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
                                                 const ChanFwd cf = s_ch[m0 + i * 16 + ch];
 #pragma unroll

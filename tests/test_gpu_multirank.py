@@ -44,8 +44,10 @@ def test_engine_two_ranks_equal_single_rank(tmp_path, task):
         eng.step(); losses.append(eng.losses())
     p1 = eng.params.cpu().numpy()
     # same samples, same update; the gradient sum is formed in a different order (two partial sums + all-reduce), and the NLL rides the
-    # all-reduce as a float
-    assert np.abs(z["params"] - p1).max() < 2e-5 and np.abs(z["params"] - p1).mean() < 1e-7
+    # all-reduce as a float.  Adam turns the rounding noise of a near-zero gradient element into a step of up to lr, so: mean tight,
+    # max bounded by steps * lr (the same reading as tests/test_gpu_runner.py::test_engine_steps_match_oracle)
+    d = np.abs(z["params"] - p1)
+    assert d.max() < 1e-3 * steps and d.mean() < 1e-6, (d.max(), d.mean())
     assert np.allclose(z["losses"], np.array(losses), rtol=2e-6)
     if task == "ct":
         assert int(z["t_applied"]) == steps            # the NaN guard read the all-reduced scalar and let every update through
