@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json): MC-forward-passes/s and ELBO-iterations/s of the MFVI deep-image-prior
-denoising fit, 256x256 skip net, K=16 MC samples per GPU (configs[1]: test_configs/mfvi_den.json values).
+"""Headline benchmark (BASELINE.json): MC-forward-passes/s and ELBO-iterations/s of the MFVI deep-image-prior fit.
 
-One step = one tempered-ELBO iteration: input perturbation, K MC forwards, Gaussian NLL, backward, KL(+grad), Adam
-(and, for N > 1 ranks, the single all-reduce of the flat gradient buffer).  Weak scaling: every rank evaluates its own
-K=16 samples (eps keyed by the global sample index), so the job evaluates 16*N samples per iteration.
+Default workload = configs[1]: test_configs/mfvi_den.json values, 256x256 skip net, K = 16 MC samples per GPU.
+One step = one tempered-ELBO iteration: input perturbation, weight draw, K MC forwards, data term, backward, KL(+grad), Adam (and, for
+N > 1 ranks, the single all-reduce of the flat gradient buffer).
 
-    python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg5|inp] [--scaling weak|strong]
+                                                   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-Prints ONE JSON line on rank 0.  Data are synthetic (seeded phantom + noise), weights random-init; inputs are resident
-in HBM before the timed region.
+--scaling weak (default): every rank evaluates its own K samples (eps keyed by the global sample index): K * N samples per iteration.
+--scaling strong: the config's K is the job's total, split over the ranks (cfg3 as BASELINE states it: K = 32 over 4 GPUs).
+With N > 1 and the default weak mode the JSON line also carries a `strong_scaling` object (K total = the config's K) measured right after
+the timed region, so one driver run records both curves.
+
+Prints ONE JSON line on rank 0.  Data are synthetic (seeded phantom + noise from the package's own generator), weights random-init;
+inputs are resident in HBM before the timed region.
 """
 import argparse
 import json
@@ -20,11 +25,30 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# test_configs/mfvi_den.json:5,9,15-18
-DEN = dict(temp=5.656911698337764e-07, sigma=1.4616642493692077e-05, lr=1e-3, seed=1, p_sigma=0.1, input_depth=16)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector == FP32-input MFMA peak
 PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd", 5: "grad_finalize", 6: "sample_weights"}
+
+# hyper-parameters: test_configs/mfvi_{den,sr,ct}.json:5,9,15-18 of the reference; inpainting: configs/mfvi_inp.json
+DEN = dict(temp=5.656911698337764e-07, sigma=1.4616642493692077e-05, lr=1e-3, seed=1, p_sigma=0.1)
+SR = dict(temp=4.381719802264805e-07, sigma=4.9e-08, lr=1e-3, seed=2, p_sigma=0.1)
+CT = dict(temp=2.2e-10, sigma=1.7e-7, lr=1e-3, seed=1, p_sigma=0.1)
+INP = dict(temp=1e-12, sigma=0.0006506274185234421, lr=2e-3, seed=2, p_sigma=0.1)
+# BASELINE.json configs (K = MC samples per GPU in weak mode / per job in strong mode; spl = samples per launch)
+CONFIGS = {
+    "cfg1": dict(task="den", size=128, k=4, input_depth=16, hp=DEN, cpu_samples=64,
+                 what="configs[0]: mfvi_den.json on one 128x128 grayscale slice, K=4 (the reference's CPU-runnable plumbing case)"),
+    "cfg2": dict(task="den", size=256, k=16, input_depth=16, hp=DEN, cpu_samples=32,
+                 what="configs[1]: mfvi_den.json hyper-parameters, 256x256 grayscale, K=16 MC samples per GPU, 26-layer skip net, single fused-HIP path"),
+    "cfg3": dict(task="sr", size=512, k=8, k_strong=32, input_depth=32, hp=SR, cpu_samples=8,
+                 what="configs[2]: mfvi_sr.json, 4x super-resolution, 512x512 target / 128x128 observation, input depth 32; K=32 over 4 GPUs = 8 per GPU"),
+    "cfg4": dict(task="ct", size=256, k=16, input_depth=16, hp=CT, cpu_samples=32,
+                 what="configs[3]: mfvi_ct.json, 256x256, 45-angle Radon forward / back-projection in HIP, one image per GPU, K=16"),
+    "cfg5": dict(task="den", size=512, k=64, spl=16, input_depth=16, hp=DEN, cpu_samples=8, param_dtype="bf16",
+                 what="configs[4]: one 512x512 denoising fit per GPU, K=64 (4 launches of 16), bf16 mu/rho with fp32 KL terms summed in fp64"),
+    "inp": dict(task="inp", size=256, k=16, input_depth=16, hp=INP, cpu_samples=0,
+                what="inpainting MFVI variant (SURVEY 8f rank 2): 6-scale no-skip net, 5x5 down filters, nearest upsampling, 256x256 colour image, K=16"),
+}
 
 
 def conv_cost(prog, op_index, n_samples):
@@ -41,29 +65,64 @@ def conv_cost(prog, op_index, n_samples):
     return dict(bytes=bytes_, flops=flops, desc="%dx%d conv %d->%d @%dx%d s%d" % (k, k, ti["C"], to["C"], to["H"], to["W"], o["stride"]))
 
 
-def cpu_baseline(size, n_samples=2):
-    """The CPU oracle (oracle/, the restatement of the reference path; kind = "port") timed on the host cores for a
-    bounded sample of the same workload: n_samples MC passes (forward + loss + backward, then KL and one Adam step)."""
+def cpu_baseline(cfg, n_samples):
+    """The CPU oracle (oracle/, the restatement of the reference path; kind = "port") timed on the host cores for a bounded sample of
+    the same workload: n_samples MC passes (forward + data term + backward, then KL and one Adam step) of the config's net."""
     import numpy as np
     from oracle import oracle as O
-    net = O.make_net(size, size)
-    mu, rho, bnp = O.init_params(net, DEN["seed"])
-    z = (0.1 * O.uniform_fill(DEN["seed"], 0, 0, 0, 16 * size * size)).reshape(16, size, size)
-    tgt = O.noisy(O.phantom(size, size, DEN["seed"]), DEN["p_sigma"], DEN["seed"])
-    ps = float(np.float32(np.sqrt(DEN["temp"]) * DEN["sigma"] + 1e-6))
+    S, hp, task = cfg["size"], cfg["hp"], cfg["task"]
+    n_out = 1 if task == "ct" else 2
+    net = O.make_net(S, S, input_depth=cfg["input_depth"], n_out=n_out)
+    mu, rho, bnp = O.init_params(net, hp["seed"])
+    z = (0.1 * O.uniform_fill(hp["seed"], 0, 0, 0, cfg["input_depth"] * S * S)).reshape(cfg["input_depth"], S, S)
+    img = O.phantom(S, S, hp["seed"])
+    tgt = O.noisy(img, hp["p_sigma"], hp["seed"]); theta = None; tcode = 0
+    if task == "sr":
+        tgt = np.ascontiguousarray(img[::4, ::4]); tcode = 1
+    elif task == "ct":
+        theta = np.arange(0, 180., 4., dtype=np.float32); tgt = O.radon_fwd(img, theta); tcode = 2
+    ps = float(np.float32(np.sqrt(hp["temp"]) * hp["sigma"] + 1e-6))
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = O.set_threads(min(avail, 16))          # the GPU box gives one GPU a 16-core CPU share
     t0 = time.perf_counter()
-    r = O.elbo_grad(net, mu, rho, bnp, z, tgt, seed=DEN["seed"], step=0, K=n_samples, temp=DEN["temp"], prior_sigma=ps)
+    r = O.elbo_grad(net, mu, rho, bnp, z, tgt, task=tcode, factor=4, theta_deg=theta, seed=hp["seed"], step=0, K=n_samples, temp=hp["temp"], prior_sigma=ps)
     p = np.concatenate([mu, rho, bnp]); g = np.concatenate([r["dmu"], r["drho"], r["dbn"]])
-    O.adam(p, g, np.zeros_like(p), np.zeros_like(p), DEN["lr"], 1)
+    O.adam(p, g, np.zeros_like(p), np.zeros_like(p), hp["lr"], 1)
     dt = time.perf_counter() - t0
     return dict(value=n_samples / dt, unit="MC-forward-passes/s", cores=cores, kind="port",
-                sample="%d MC passes (fwd+NLL+bwd) + KL + Adam of the %dx%d den net, C oracle with OpenMP on %d host threads, %.1f s"
-                       % (n_samples, size, size, cores, dt))
+                sample="%d MC passes (fwd + data term + bwd) + KL + Adam of the %dx%d %s net, C oracle with OpenMP on %d host threads, %.1f s"
+                       % (n_samples, S, S, task, cores, dt))
+
+
+def make_engine(cfg, K, rank, world, torch):
+    """Engine + synthetic target of a config, inputs from the package's own generator (runner.phantom)."""
+    import numpy as np
+    from mfvi_dip_mia_amd import _lib as L
+    from mfvi_dip_mia_amd.engine import ElboEngine
+    from mfvi_dip_mia_amd.runner import phantom
+    S, hp, task = cfg["size"], cfg["hp"], cfg["task"]
+    kw = dict(param_dtype=cfg["param_dtype"]) if "param_dtype" in cfg else {}
+    eng = ElboEngine(S, S, task=task, K=K, input_depth=cfg["input_depth"], temp=hp["temp"], sigma=hp["sigma"], lr=hp["lr"], seed=hp["seed"],
+                     rank=rank, world_size=world, samples_per_launch=cfg.get("spl"), **kw)
+    rng = np.random.default_rng(hp["seed"] + 1)
+    if task == "inp":
+        img = np.stack([phantom(S, S, hp["seed"] + c) for c in range(3)])
+        mask = (rng.random((1, S, S)) > 0.12).astype(np.float32)
+        eng.set_target(torch.from_numpy(img), torch.from_numpy(mask))
+        return eng
+    img = phantom(S, S, hp["seed"])
+    if task == "den":
+        tgt = torch.from_numpy(np.clip(img + rng.normal(scale=hp["p_sigma"], size=img.shape), 0, 1).astype(np.float32))
+    elif task == "sr":
+        tgt = torch.from_numpy(np.ascontiguousarray(img[::4, ::4]))
+    else:
+        tgt = torch.empty((eng.theta.numel(), S), device="cuda")
+        L.check(L.lib().mfvi_radon_forward(L.ptr(torch.from_numpy(img).cuda()), L.ptr(eng.theta), 1, S, S, eng.theta.numel(), L.ptr(tgt), L.stream_ptr()))
+    eng.set_target(tgt)
+    return eng
 
 
 def main():
@@ -71,11 +130,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--k", type=int, default=16, help="MC samples per GPU per iteration")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--size", type=int, default=None, help="override the config's image size")
+    ap.add_argument("--k", type=int, default=None, help="override the config's MC samples (per GPU in weak mode, per job in strong mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel time table of one iteration to stderr")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.size:
+        cfg["size"] = args.size
+    if args.k:
+        cfg["k"] = args.k; cfg.pop("k_strong", None)
 
     import torch
     import torch.distributed as dist
@@ -88,20 +154,20 @@ def main():
     # driver's runs use the default: one rank per GPU over RCCL
     backend = os.environ.get("MFVI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
-    pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)         # "nccl" is RCCL on ROCm
 
     import mfvi_dip_mia_amd as M
-    from mfvi_dip_mia_amd.engine import ElboEngine
     M._lib.lib()       # no library, no benchmark: fail loudly
-    from oracle import oracle as O     # synthetic inputs only (phantom + noise); nothing timed comes from the oracle
 
-    S, K = args.size, args.k
-    eng = ElboEngine(S, S, task="den", K=K * world, input_depth=DEN["input_depth"], temp=DEN["temp"], sigma=DEN["sigma"],
-                     lr=DEN["lr"], seed=DEN["seed"], rank=rank, world_size=world, process_group=pg)
-    eng.set_target(torch.from_numpy(O.noisy(O.phantom(S, S, DEN["seed"]), DEN["p_sigma"], DEN["seed"])))
+    S = cfg["size"]
+    strong = args.scaling == "strong"
+    k_strong = cfg.get("k_strong", cfg["k"])
+    K_total = k_strong if strong else cfg["k"] * world
+    if K_total % world:
+        sys.exit("K = %d MC samples do not split over %d ranks" % (K_total, world))
+    eng = make_engine(cfg, K_total, rank, world, torch)
 
     def barrier():
         if world > 1:
@@ -113,7 +179,7 @@ def main():
         eng.step()
     torch.cuda.synchronize()
     # (the instrumented iteration runs every kernel ALONE on the stream: in the timed region the backward-weight kernels overlap the
-    #  backward-data / fold chain on the plan's side stream, which stretches the launches that share the chip)
+    #  backward-data / concat chain on the plan's side stream, which stretches the launches that share the chip)
     eng.plan.side_stream(False)
     eng.plan.profile(1)
     eng.step()
@@ -124,6 +190,7 @@ def main():
     by = {}
     for op, ps_, ms in recs:
         by[(op, ps_)] = by.get((op, ps_), 0.0) + ms
+    n_launch = max(1, (eng.K_local + eng.chunk - 1) // eng.chunk)        # launches of a kernel per iteration (cfg5: 4)
     (dom_op, dom_pass), dom_ms = max(((k_, v) for k_, v in by.items() if k_[1] in (0, 1, 2) and k_[0] >= 0 and conv_cost(eng.prog, k_[0], 1)), key=lambda kv: kv[1])
     if args.profile_all and rank == 0:
         tot = sum(by.values())
@@ -136,7 +203,8 @@ def main():
             sys.stderr.write("  %-22s %8.3f ms %5.1f%%\n" % (kind, ms, 100 * ms / tot))
         for (op, ps_), ms in sorted(by.items(), key=lambda kv: -kv[1])[:(200 if os.environ.get('MFVI_PROFILE_FULL') else 24)]:
             c = conv_cost(eng.prog, op, eng.chunk) if op >= 0 else None
-            rate = "  %6.1f TFLOP/s %6.0f GB/s(alg)" % (c["flops"] / ms / 1e9, c["bytes"] / ms / 1e6) if c and ps_ in (0, 1, 2) else ""
+            ms1 = ms / n_launch
+            rate = "  %6.1f TFLOP/s %6.0f GB/s(alg)" % (c["flops"] / ms1 / 1e9, c["bytes"] / ms1 / 1e6) if c and ps_ in (0, 1, 2) else ""
             sys.stderr.write("op %2d %-10s %8.3f ms %5.1f%%  %s%s\n" % (op, PASS_NAMES[ps_], ms, 100 * ms / tot, c["desc"] if c else ("all layers" if op < 0 else "concat_up"), rate))
         sys.stderr.write("sum of kernel times in one iteration: %.3f ms\n" % tot)
 
@@ -149,10 +217,10 @@ def main():
     # ELBO iterations WITH the reference loop's per-iteration bookkeeping (EMA, clips, ring buffers, 2 MSE + 3 PSNR + 3 SSIM:
     # bayesian_optimization.py:1374-1406) — SURVEY 8(d)(ii) asks for the rate with and without it (extra information, untimed region)
     with_book = None
-    if world == 1:
-        from mfvi_dip_mia_amd.runner import _Book
-        gt = O.phantom(S, S, DEN["seed"])
-        book = _Book(eng, 16, gt, O.noisy(gt, DEN["p_sigma"], DEN["seed"]))
+    if world == 1 and cfg["task"] == "den":
+        from mfvi_dip_mia_amd.runner import _Book, phantom
+        gt = phantom(S, S, cfg["hp"]["seed"])
+        book = _Book(eng, 16, gt, eng.target.cpu().numpy())
         for i in range(3):
             eng.step(); book.iteration(eng, i, eng.chunk)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -161,20 +229,34 @@ def main():
         torch.cuda.synchronize(); with_book = 10 / (time.perf_counter() - t0)
 
     # ---- timed region: exactly --steps iterations, only the dominant kernel carries events ----
+    def timed(e, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        return dt
     eng.plan.profile(2, dom_op, dom_pass)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    dt = timed(eng, args.steps)
     recs = eng.plan.profile_read()
     eng.plan.profile(0)
     nll, kl, loss = eng.losses()
+
+    # second curve of a multi-GPU weak run: the config's K split over the ranks (untimed by the contract's value, reported beside it)
+    strong_extra = None
+    if world > 1 and not strong and k_strong % world == 0:
+        eng2 = make_engine(cfg, k_strong, rank, world, torch)
+        for _ in range(args.warmup):
+            eng2.step()
+        dt2 = timed(eng2, args.steps)
+        strong_extra = dict(k_total=k_strong, k_per_rank=k_strong // world, ms_per_step=1e3 * dt2 / args.steps, value=k_strong * args.steps / dt2,
+                            unit="MC-forward-passes/s", elbo_iters_per_sec=args.steps / dt2)
+        del eng2
 
     if rank == 0:
         kms = [ms for _, _, ms in recs]
@@ -189,15 +271,19 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = None
         # the same kernel timed alone (untimed instrumented iteration, side stream off): what the kernel achieves when it has the chip
-        iso_ms = by[(dom_op, dom_pass)]
+        iso_ms = by[(dom_op, dom_pass)] / n_launch
         roof["alone"] = dict(avg_launch_ms=iso_ms, achieved=(cost["flops"] / 1e12 if roof["bound"] == "mfma" else cost["bytes"] / 1e9) / (iso_ms * 1e-3),
                              frac=(cost["flops"] / 1e12 if roof["bound"] == "mfma" else cost["bytes"] / 1e9) / (iso_ms * 1e-3) / roof["peak"])
         roof["note"] = ("achieved/frac: launch duration inside the timed region, where the backward-weight kernels run on the plan's low-priority side "
-                        "stream and share the chip with the backward-data / fold / concat chain of the caller's stream (the overlap shortens the "
-                        "iteration by 5% and stretches the individual launches); 'alone': the same kernel in the untimed instrumented iteration, side "
-                        "stream off, chip to itself")
+                        "stream and share the chip with the backward-data / concat chain of the caller's stream (the overlap shortens the "
+                        "iteration and stretches the individual launches); 'alone': the same kernel in the untimed instrumented iteration, side "
+                        "stream off, chip to itself.  algorithmic_bytes counts the layer's input, output, mu and rho once; the sampled-weight slab "
+                        "the kernel actually reads its weights from ([K][n_vi] floats written once per pass by sample_weights_kernel, DESIGN.md §5) "
+                        "adds slab_bytes to what crosses HBM / L2")
+        o = eng.prog.ops[dom_op]
+        nw = eng.prog.tensors[o["out"]]["C"] * eng.prog.tensors[o["in0"]]["C"] * o["ksize"] ** 2 + eng.prog.tensors[o["out"]]["C"]
         roof.update(kernel="%s of op %d: %s, %d samples/launch" % (PASS_NAMES[dom_pass], dom_op, cost["desc"], eng.chunk),
-                    avg_launch_ms=avg_ms, launches=len(kms), algorithmic_bytes=cost["bytes"], algorithmic_flops=cost["flops"],
+                    avg_launch_ms=avg_ms, launches=len(kms), algorithmic_bytes=cost["bytes"], algorithmic_flops=cost["flops"], slab_bytes=4 * nw * eng.chunk,
                     hbm_gbs_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9, hbm_frac_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
@@ -207,18 +293,23 @@ def main():
                 pass
         total_samples = eng.K_local * world * args.steps
         res = {
-            "metric": "MC-forward-passes/sec (each inside a full ELBO iteration: fwd+NLL+bwd+KL+Adam), %dx%d skip MFVI denoise" % (S, S),
+            "metric": "MC-forward-passes/sec (each inside a full ELBO iteration: fwd+data term+bwd+KL+Adam), %dx%d skip MFVI %s" % (S, S, cfg["task"]),
             "value": total_samples / dt, "unit": "MC-forward-passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "mfvi_den.json hyper-parameters, %dx%d grayscale, K=%d MC samples per GPU, 26-layer skip net, single fused-HIP path" % (S, S, K),
-                       "mc_samples_per_iteration": eng.K_local * world, "parallelism": "mc-sample sharding x%d, 1 all-reduce/iter" % world},
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if cfg.get("param_dtype", "f32") == "f32" else "f32 arithmetic on bf16-stored mu/rho", "data": "synthetic",
+            "config": {"workload": cfg["what"], "name": args.config, "mc_samples_per_iteration": eng.K_local * world,
+                       "mc_samples_per_gpu": eng.K_local, "parallelism": "mc-sample sharding x%d, 1 all-reduce/iter" % world},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
             "elbo_iters_per_sec": args.steps / dt, "elbo_iters_per_sec_with_bookkeeping": with_book, "fwd_only_mc_passes_per_sec": fwd_only,
             "final_loss": loss, "final_nll": nll, "final_kl": kl,
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(S, n_samples=16)
+        if strong_extra:
+            res["strong_scaling"] = strong_extra
+        if world == 1 and not args.no_cpu_baseline and cfg["cpu_samples"]:
+            res["cpu_baseline"] = cpu_baseline(cfg, cfg["cpu_samples"])
+        elif world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = None       # the oracle has no 5x5 / no-skip net driver: the inpainting variant is pinned by reference goldens only
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
