@@ -251,7 +251,7 @@ def main():
     strong_extra = None
     if world > 1 and not strong and k_strong % world == 0:
         eng2 = make_engine(cfg, k_strong, rank, world, torch)
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 6)):      # a collective's first calls on a new buffer set up staging / channels (gloo: ~0.25 s once)
             eng2.step()
         dt2 = timed(eng2, args.steps)
         strong_extra = dict(k_total=k_strong, k_per_rank=k_strong // world, ms_per_step=1e3 * dt2 / args.steps, value=k_strong * args.steps / dt2,

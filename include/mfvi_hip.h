@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct mfvi_plan mfvi_plan;
 
-enum { MFVI_OP_CONV = 1, MFVI_OP_CONCAT_UP = 2 };
+enum { MFVI_OP_CONV = 1, MFVI_OP_CONCAT_UP = 2, MFVI_OP_CONV_LRT = 3 };
 enum { MFVI_UP_BILINEAR = 0, MFVI_UP_NEAREST = 1 };   /* nn.Upsample(scale_factor=2, mode=...) (models/skip.py:102) */
 enum { MFVI_TASK_DENOISE = 0, MFVI_TASK_SR = 1 };
 enum { MFVI_PARAM_F32 = 0, MFVI_PARAM_BF16 = 1 };     /* storage of the MU / RHO blocks (mfvi_plan_set_param_dtype) */
@@ -55,6 +55,11 @@ typedef struct {
  * MFVI_OP_CONV       out = conv2d(reflection_pad(view(in0), ksize/2), w, b, stride), w = mu + softplus(rho)*eps
  *                    = ReflectionPad2d + Conv2dRT: models/common.py:100-135, BayTorch/modules/reparam_layers.py:26-37,
  *                      BayTorch/modules/module.py:82-85.
+ * MFVI_OP_CONV_LRT   the same layer with the LOCAL reparameterisation (Conv2dLRT: BayTorch/modules/reparam_layers.py:39-72, conv.py:74-106;
+ *                    MeanFieldVI(reparam='local')): with v = reflection_pad(view(in0)),
+ *                        out = conv2d(v, mu, mu_b) + sqrt(1e-16 + conv2d(v**2, softplus(rho)**2, softplus(rho_b)**2)) * eps,
+ *                    eps ~ N(0,1) in OUTPUT space: element j of [Cout][Ho][Wo] = lane j & 3 of block j >> 2 of RNG domain 7, stream
+ *                    layer_id.  sample_weights = 0: out = conv2d(v, mu, mu_b) (LRTLayer's eval branch).  Same parameters, same KL.
  * MFVI_OP_CONCAT_UP  out = cat(view(in0), upsample2x_bilinear(view(in1)))  (in0 = -1: upsample only)
  *                    = Concat + nn.Upsample: models/common.py:23-43, models/skip.py:102. */
 typedef struct {

@@ -6,8 +6,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFVI_LIB_PATH") or os.path.join(HERE, "libmfvi_hip.so")      # MFVI_LIB_PATH: an experimental build (A/B timing)
 
-OP_CONV, OP_CONCAT_UP = 1, 2
-DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD, DOMAIN_DROPOUT, DOMAIN_ROUND = 0, 1, 2, 3, 4, 5, 6
+OP_CONV, OP_CONCAT_UP, OP_CONV_LRT = 1, 2, 3
+DOMAIN_EPS, DOMAIN_INPUT, DOMAIN_INIT, DOMAIN_UNIFORM, DOMAIN_SGLD, DOMAIN_DROPOUT, DOMAIN_ROUND, DOMAIN_LRT = 0, 1, 2, 3, 4, 5, 6, 7
 PARAM_F32, PARAM_BF16 = 0, 1
 
 

@@ -6,12 +6,12 @@ from . import engine, sharding
 from . import runner
 from .nets import Concat, get_net, skip
 
-__all__ = ["build", "Plan", "Program", "skip_program", "_lib", "engine", "sharding", "runner", "Concat", "get_net", "skip", "MeanFieldVI", "FusedNet", "Conv2dRT",
+__all__ = ["build", "Plan", "Program", "skip_program", "_lib", "engine", "sharding", "runner", "Concat", "get_net", "skip", "MeanFieldVI", "FusedNet", "Conv2dRT", "Conv2dLRT",
            "gaussian_nll", "gaussian_nll_inpainting"]
 
 
 def __getattr__(name):          # bayes.py needs torch.nn at import: keep `import mfvi_dip_mia_amd` light
-    if name in ("MeanFieldVI", "FusedNet", "Conv2dRT", "gaussian_nll", "gaussian_nll_inpainting"):
+    if name in ("MeanFieldVI", "FusedNet", "Conv2dRT", "Conv2dLRT", "gaussian_nll", "gaussian_nll_inpainting"):
         from . import bayes
         return getattr(bayes, name)
     raise AttributeError(name)

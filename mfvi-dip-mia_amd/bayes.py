@@ -47,6 +47,11 @@ class Conv2dRT(nn.Module):
         raise RuntimeError("Conv2dRT layers are executed by the owning MeanFieldVI through the fused HIP layer program")
 
 
+class Conv2dLRT(Conv2dRT):
+    """The same parameter holder for the local-reparameterisation layer (BayTorch/modules/conv.py:74-106): sampling happens in
+    activation space, parameters and KL are those of Conv2dRT."""
+
+
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, x, *params):
@@ -76,9 +81,9 @@ class MeanFieldVI(nn.Module):
     def __init__(self, net, prior=None, posteriors=None, kl_type='reverse', reparam='local', replace_layers='all',
                  device=torch.device('cpu'), seed=None, n_samples=1):
         super().__init__()
-        if reparam == 'local':
-            raise NotImplementedError("local reparameterisation (Conv2dLRT) is not built: every MFVI runner of the reference "
-                                      "passes reparam='' (bayesian_optimization.py:543,1342,2158,3007)")
+        # reparam == 'local' (the reference's default): every conv becomes a Conv2dLRT (sampling in activation space); anything else
+        # (the runners pass ''): Conv2dRT (sampling in weight space) — freq_to_bayes.py:22-29
+        self._lrt = reparam == 'local'
         if replace_layers != 'all':
             raise NotImplementedError("replace_layers=%r: only 'all' (the runners' setting) is built" % (replace_layers,))
         if kl_type != 'reverse':
@@ -113,7 +118,7 @@ class MeanFieldVI(nn.Module):
             elif isinstance(m, nn.Conv2d):
                 if m.groups != 1 or m.dilation != (1, 1) or m.padding != (0, 0):
                     raise NotImplementedError("Conv2d with groups/dilation/own padding is outside the skip() family")
-                module._modules[key] = Conv2dRT(m.in_channels, m.out_channels, m.kernel_size, torch.is_tensor(m.bias), m.stride,
+                module._modules[key] = (Conv2dLRT if self._lrt else Conv2dRT)(m.in_channels, m.out_channels, m.kernel_size, torch.is_tensor(m.bias), m.stride,
                                                 m.padding, m.dilation, m.groups, prior, posteriors, kl_type, self)
             elif isinstance(m, (nn.Linear, nn.Conv3d)):
                 raise NotImplementedError("Linear / Conv3d Bayesian layers are not part of the inverse-problem nets")
@@ -246,7 +251,7 @@ class MeanFieldVI(nn.Module):
                 stride = m.kwargs['stride'] if isinstance(m, Conv2dRT) else m.stride
                 stride = stride[0] if isinstance(stride, (tuple, list)) else stride
                 out = P.tensor(m.out_channels, *P.conv_out_hw(v['tid'], k, stride))
-                P.conv(v['tid'], out, k, stride, bias=m._has_bias)
+                P.conv(v['tid'], out, k, stride, bias=m._has_bias, lrt=self._lrt)
                 lay = P.layers[-1]
                 if lay['w_off'] != m._w_off or lay['b_off'] != m._b_off:
                     fail("internal: parameter offsets out of sync")
@@ -427,6 +432,7 @@ class FusedNet(MeanFieldVI):
         self._token = 0
         self._plans = {}
         self._sampling = False                                   # w = weight: RTLayer's eval branch of the kernels
+        self._lrt = False
         self._drops = [m for m in net.modules() if isinstance(m, nn.Dropout2d)]
         for m in net.modules():
             if isinstance(m, (nn.Linear, nn.Conv3d, nn.Dropout)) and not isinstance(m, nn.Dropout2d):

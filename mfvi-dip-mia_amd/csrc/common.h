@@ -85,7 +85,7 @@ __device__ __forceinline__ void spec_boxmuller(uint32_t a, uint32_t b, float& z0
     z1 = rad * sn;
 }
 
-enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4, DOMAIN_DROPOUT = 5, DOMAIN_ROUND = 6 };
+enum { DOMAIN_EPS = 0, DOMAIN_INPUT = 1, DOMAIN_INIT = 2, DOMAIN_UNIFORM = 3, DOMAIN_SGLD = 4, DOMAIN_DROPOUT = 5, DOMAIN_ROUND = 6, DOMAIN_LRT = 7 };
 
 struct RngKey {              // everything but the block index
     uint32_t k0, k1;         // seed lo/hi
@@ -193,10 +193,14 @@ __device__ __forceinline__ ChanFwd chan_fwd(const TView& v, int k, int c)
     r.mean = (float)m; r.scale = (float)(rstd * (double)v.gamma[c]); r.beta = v.gamma[v.C + c]; r.rstd = (float)rstd;
     return r;
 }
+// act: bit 0 = LeakyReLU(slope) after the BN; bit 1 (MFVI_ACT_SQUARE) = square the result — the x**2 operand of the local-reparameterisation
+// layers' variance convolution (BayTorch/modules/reparam_layers.py:69), set by the plan on the view it hands to that convolution only
+#define MFVI_ACT_SQUARE 2
 __device__ __forceinline__ float apply_fwd(const ChanFwd& c, float y, int act, float slope)
 {
     float v = __builtin_fmaf(y - c.mean, c.scale, c.beta);
-    if (act) v = v > 0.f ? v : v * slope;
+    if (act & 1) v = v > 0.f ? v : v * slope;
+    if (act & MFVI_ACT_SQUARE) v = v * v;
     return v;
 }
 __device__ __forceinline__ ChanBwd chan_bwd(const GView& g, int k, int c)
@@ -331,10 +335,24 @@ int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blo
                          int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const void* mu,
                          hipStream_t st, int bf16 = 0);
 constexpr int GRAD_FIN_QUADS = 64;      // weight quads per block of the finalize kernel
-struct FoldSrc { const float* d; long long sstride; int pad; };
+// mul2v: the source is the gradient wrt view(X)**2 (variance convolution of an LRT layer): it enters with the factor 2 * view(X)
+struct FoldSrc { const float* d; long long sstride; int pad; int mul2v; };
+constexpr int MAX_FOLD_SRC = 4;      // two consumers, each an RT (one source) or an LRT (two sources) convolution
+struct FoldSrcs { FoldSrc s[MAX_FOLD_SRC]; int n; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.
 int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,
                        int n_samples, hipStream_t st);
+// ---- local reparameterisation (LRTLayer.forward, BayTorch/modules/reparam_layers.py:59-72) around two ordinary convolutions ----
+// sig2[j] = softplus(rho[j])^2 for j in [0, n): the weights / bias of the variance convolution
+int launch_lrt_sigma2(const float* rho, long long n, float* sig2, hipStream_t st);
+// y = a + sqrt(1e-16 + s2) * eps, eps = N(0,1) of RNG domain LRT, stream layer_id, sample k0 + k, element index over [C][HW];
+// accumulates the statistics of the BatchNorm that follows y
+int launch_lrt_combine(const float* a, const float* s2, long long sstride, int C, long long HW, RngKey key, int layer_id, OutDesc y,
+                       int n_samples, hipStream_t st);
+// ds2 = dy * eps / (2 sqrt(1e-16 + s2)), dy formed from gy (BN-backward on load)
+int launch_lrt_ds2(const GView& gy, const float* s2, long long sstride, RngKey key, int layer_id, float* ds2, int n_samples, hipStream_t st);
+// drho[j] += dsig2[j] * 2 softplus(rho[j]) sigmoid(rho[j])
+int launch_lrt_drho(const float* dsig2, const float* rho, long long n, float* drho, hipStream_t st);
 int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int nearest, int n_samples, hipStream_t st);
 int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long ga_a_sstride, double* bsums_a,
                          const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int nearest, int n_samples, hipStream_t st);

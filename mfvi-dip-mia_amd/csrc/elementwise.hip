@@ -14,10 +14,11 @@ namespace {
 constexpr int EW_ITEMS = 4;     // pixels per thread
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrc s0, FoldSrc s1, int n_src, TView x,
+__global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrcs S, TView x,
                                                           float* __restrict__ ga, long long ga_sstride,
                                                           double* __restrict__ bsums)
 {
+    const int n_src = S.n;
     __shared__ ChanFwd s_ch;
     __shared__ double s_red[8];
     const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
@@ -35,23 +36,28 @@ __global__ __launch_bounds__(256) void finalize_dx_kernel(FoldSrc s0, FoldSrc s1
         if (pix >= HW) break;
         const int r = (int)(pix / W), q = (int)(pix - (long long)r * W);
         float d = 0.f;
+        // view(x) at this pixel: the factor of the sources that carry the gradient wrt view(x)**2
+        const float vx = apply_fwd(ch, yx[pix], x.act & 1, x.slope);
         for (int s = 0; s < n_src; ++s) {
-            const FoldSrc src = s == 0 ? s0 : s1;
+            const FoldSrc src = S.s[s];
             const int p = src.pad, Hp = H + 2 * p, Wp = W + 2 * p;
             const float* __restrict__ base = src.d + (long long)k * src.sstride + (long long)c * Hp * Wp;
-            if (p == 0) { d += base[(long long)r * Wp + q]; continue; }
+            const float mul = src.mul2v ? 2.f * vx : 1.f;
+            if (p == 0) { d += mul * base[(long long)r * Wp + q]; continue; }
             // padded rows that fold onto r under ReflectionPad2d(p): r+p always; p-r for 1 <= r <= p (top mirror);
             // p + 2(H-1) - r for H-1-p <= r <= H-2 (bottom mirror).  Columns alike.
             int rows[3], cols[3], nr = 0, nc = 0;
             rows[nr++] = r + p; if (r >= 1 && r <= p) rows[nr++] = p - r; if (r >= H - 1 - p && r <= H - 2) rows[nr++] = p + 2 * (H - 1) - r;
             cols[nc++] = q + p; if (q >= 1 && q <= p) cols[nc++] = p - q; if (q >= W - 1 - p && q <= W - 2) cols[nc++] = p + 2 * (W - 1) - q;
+            float e = 0.f;
             for (int a = 0; a < nr; ++a)
-                for (int b = 0; b < nc; ++b) d += base[(long long)rows[a] * Wp + cols[b]];
+                for (int b = 0; b < nc; ++b) e += base[(long long)rows[a] * Wp + cols[b]];
+            d += mul * e;
         }
         if (has_bn) {
             const float yv = yx[pix];
             const float v = __builtin_fmaf(yv - ch.mean, ch.scale, ch.beta);
-            if (x.act && !(v > 0.f)) d *= x.slope;
+            if ((x.act & 1) && !(v > 0.f)) d *= x.slope;
             sg += (double)d; sgx += (double)d * (double)((yv - ch.mean) * ch.rstd);
         }
         gout[pix] = d;
@@ -89,7 +95,7 @@ __device__ __forceinline__ float4 fold_row4(const float* __restrict__ base, int 
 __global__ __launch_bounds__(256) void finalize_dx_vec_kernel(FoldSrc s0, FoldSrc s1, int n_src, TView x,
                                                               float* __restrict__ ga, long long ga_sstride,
                                                               double* __restrict__ bsums)
-{
+{   // (the float4 kernel serves the RT layers: at most two plain sources; LRT sources take the scalar kernel)
     __shared__ ChanFwd s_ch;
     __shared__ double s_red[8];
     const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void finalize_dx_vec_kernel(FoldSrc s0, FoldSr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = __builtin_fmaf(yy[j] - ch.mean, ch.scale, ch.beta);
-                if (x.act && !(v > 0.f)) dd[j] *= x.slope;
+                if ((x.act & 1) && !(v > 0.f)) dd[j] *= x.slope;
                 sg += (double)dd[j]; sgx += (double)dd[j] * (double)((yy[j] - ch.mean) * ch.rstd);
             }
         }
@@ -417,12 +423,79 @@ __global__ void bn_param_grads_kernel(const BnGradEntry* __restrict__ table, con
     }
 }
 
+// ---- local reparameterisation (BayTorch/modules/reparam_layers.py:59-72) ---------------------------------------------------
+__global__ __launch_bounds__(256) void lrt_sigma2_kernel(const float* __restrict__ rho, long long n, float* __restrict__ sig2)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float s = softplus_f(rho[i]);
+        sig2[i] = s * s;
+    }
+}
+__global__ __launch_bounds__(256) void lrt_drho_kernel(const float* __restrict__ dsig2, const float* __restrict__ rho, long long n, float* __restrict__ drho)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = dsig2[i];
+        if (d != 0.f) { const float r = rho[i]; drho[i] += d * 2.f * softplus_f(r) * sigmoid_f(r); }
+    }
+}
+// eps of element j = c * HW + p of the layer's output: lane j & 3 of Philox block j >> 2 (RNG domain LRT, stream layer_id, sample k0 + k)
+__device__ __forceinline__ void lrt_eps4(RngKey key, int layer_id, int k, long long j0, float z[4])
+{
+    key.stream = ((uint32_t)DOMAIN_LRT << 24) | (uint32_t)layer_id; key.sample += (uint32_t)k;
+    spec_normal4(key, (uint32_t)(j0 >> 2), z);
+}
+__global__ __launch_bounds__(256) void lrt_combine_kernel(const float* __restrict__ a, const float* __restrict__ s2, long long sstride, int C, long long HW,
+                                                          RngKey key, int layer_id, OutDesc y)
+{
+    __shared__ double s_red[8];
+    const int k = blockIdx.z, c = blockIdx.y;
+    const float* __restrict__ ap = a + (long long)k * sstride + (long long)c * HW;
+    const float* __restrict__ sp = s2 + (long long)k * sstride + (long long)c * HW;
+    float* __restrict__ yp = y.data + (long long)k * y.sstride + (long long)c * HW;
+    double sum = 0.0, sq = 0.0;
+    // 4 consecutive elements per thread; (c * HW + p) & 3 need not be 0, so every element looks up its own Philox block lane
+    for (int it = 0; it < 4; ++it) {
+        const long long p = ((long long)blockIdx.x * 4 + it) * 256 + threadIdx.x;
+        if (p >= HW) break;
+        const long long j = (long long)c * HW + p;
+        float z[4]; lrt_eps4(key, layer_id, k, j, z);
+        const float v = ap[p] + sqrtf(1e-16f + sp[p]) * z[j & 3];
+        yp[p] = v; sum += (double)v; sq += (double)v * (double)v;
+    }
+    if (y.stats) {
+        const double s0 = block_sum_d(sum, s_red);
+        const double s1 = block_sum_d(sq, s_red);
+        if (threadIdx.x == 0) { double* o = y.stats + ((long long)k * C + c) * 2; atomicAdd(o, s0); atomicAdd(o + 1, s1); }
+    }
+}
+__global__ __launch_bounds__(256) void lrt_ds2_kernel(GView gy, const float* __restrict__ s2, long long sstride, long long HW, RngKey key, int layer_id,
+                                                      float* __restrict__ ds2)
+{
+    __shared__ ChanBwd s_cb;
+    const int k = blockIdx.z, c = blockIdx.y;
+    if (threadIdx.x == 0) s_cb = chan_bwd(gy, k, c);
+    __syncthreads();
+    const ChanBwd cb = s_cb;
+    const float* __restrict__ gp = gy.ga + (long long)k * gy.gstride + (long long)c * HW;
+    const float* __restrict__ yp = gy.y ? gy.y + (long long)k * gy.ystride + (long long)c * HW : nullptr;
+    const float* __restrict__ sp = s2 + (long long)k * sstride + (long long)c * HW;
+    float* __restrict__ dp = ds2 + (long long)k * sstride + (long long)c * HW;
+    for (int it = 0; it < 4; ++it) {
+        const long long p = ((long long)blockIdx.x * 4 + it) * 256 + threadIdx.x;
+        if (p >= HW) break;
+        const long long j = (long long)c * HW + p;
+        float z[4]; lrt_eps4(key, layer_id, k, j, z);
+        const float dy = (gy.stats && yp) ? apply_bwd(cb, gp[p], yp[p]) : gp[p];
+        dp[p] = dy * z[j & 3] / (2.f * sqrtf(1e-16f + sp[p]));
+    }
+}
+
 }  // namespace
 
 int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,
                        int n_samples, hipStream_t st)
 {
-    if (n_src < 1 || n_src > 2) { set_error("finalize_dx: %d gradient sources (1..2 supported)", n_src); return -1; }
+    if (n_src < 1 || n_src > MAX_FOLD_SRC) { set_error("finalize_dx: %d gradient sources (1..%d supported)", n_src, MAX_FOLD_SRC); return -1; }
     for (int i = 0; i < n_src; ++i)
         if (srcs[i].pad < 0 || srcs[i].pad > 2) { set_error("finalize_dx: pad %d unsupported", srcs[i].pad); return -1; }
     for (int i = 0; i < n_src; ++i)
@@ -430,14 +503,47 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
     const long long HW = (long long)x.H * x.W;
     FoldSrc s0 = srcs[0], s1 = n_src > 1 ? srcs[1] : srcs[0];
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const int maxpad = n_src > 1 ? (srcs[0].pad > srcs[1].pad ? srcs[0].pad : srcs[1].pad) : srcs[0].pad;      // the float4 kernel folds pad <= 1
-    if (maxpad <= 1 && (x.W & 3) == 0 && x.H >= 2 && ((x.sstride | ga_sstride) & 3) == 0 && al16(x.data) && al16(ga)) {
+    int maxpad = 0, any_mul = 0;
+    for (int i = 0; i < n_src; ++i) { if (srcs[i].pad > maxpad) maxpad = srcs[i].pad; any_mul |= srcs[i].mul2v; }      // the float4 kernel folds pad <= 1
+    if (n_src <= 2 && !any_mul && maxpad <= 1 && (x.W & 3) == 0 && x.H >= 2 && ((x.sstride | ga_sstride) & 3) == 0 && al16(x.data) && al16(ga)) {
         dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), x.C, n_samples);
         hipLaunchKernelGGL(finalize_dx_vec_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
         return (int)hipGetLastError();
     }
     dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), x.C, n_samples);
-    hipLaunchKernelGGL(finalize_dx_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
+    FoldSrcs S; S.n = n_src;
+    for (int i = 0; i < MAX_FOLD_SRC; ++i) S.s[i] = srcs[i < n_src ? i : 0];
+    hipLaunchKernelGGL(finalize_dx_kernel, grid, dim3(256), 0, st, S, x, ga, ga_sstride, bsums);
+    return (int)hipGetLastError();
+}
+
+int launch_lrt_sigma2(const float* rho, long long n, float* sig2, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lrt_sigma2_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st, rho, n, sig2);
+    return (int)hipGetLastError();
+}
+
+int launch_lrt_combine(const float* a, const float* s2, long long sstride, int C, long long HW, RngKey key, int layer_id, OutDesc y,
+                       int n_samples, hipStream_t st)
+{
+    dim3 grid((unsigned)((HW + 1023) / 1024), C, n_samples);
+    hipLaunchKernelGGL(lrt_combine_kernel, grid, dim3(256), 0, st, a, s2, sstride, C, HW, key, layer_id, y);
+    return (int)hipGetLastError();
+}
+
+int launch_lrt_ds2(const GView& gy, const float* s2, long long sstride, RngKey key, int layer_id, float* ds2, int n_samples, hipStream_t st)
+{
+    const long long HW = (long long)gy.H * gy.W;
+    dim3 grid((unsigned)((HW + 1023) / 1024), gy.C, n_samples);
+    hipLaunchKernelGGL(lrt_ds2_kernel, grid, dim3(256), 0, st, gy, s2, sstride, HW, key, layer_id, ds2);
+    return (int)hipGetLastError();
+}
+
+int launch_lrt_drho(const float* dsig2, const float* rho, long long n, float* drho, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lrt_drho_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st, dsig2, rho, n, drho);
     return (int)hipGetLastError();
 }
 

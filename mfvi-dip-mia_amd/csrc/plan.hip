@@ -35,6 +35,7 @@ struct OpInfo {
     mfvi_op_desc d;
     ConvGeom g;
     long long scratch_off = -1;                // floats: padded input-gradient scratch of this conv
+    long long scratch2_off = -1, s2_off = -1;  // LRT: padded scratch of the variance convolution's input gradient; s2 = conv(v^2, sigma^2) kept for the backward
     long long part_off = -1, part_stride = 0;  // floats: partial-dW slabs of the MFMA backward-weight kernel [strip][sample][stride]
     int max_strips = 0;
 };
@@ -57,6 +58,9 @@ struct mfvi_plan {
     int param_dtype = MFVI_PARAM_F32;          // storage of mu / rho handed to forward / backward (MFVI_PARAM_BF16: bf16_t arrays)
     int n_generic = 0;                         // conv layers outside the sampling table (served by the generic fp32 kernels)
     long long p32_off = -1;                    // floats: [mu | rho] expanded to float32 for those kernels when mu / rho are bf16
+    int n_lrt = 0;                             // local-reparameterisation layers
+    long long sig2_off = -1, dsig2_off = -1;   // floats [n_vi] each: softplus(rho)^2 of this pass / gradient wrt it
+    long long lrt_tmp_off = -1, lrt_tmp_n = 0; // floats: mean-convolution output (forward) / ds2 (backward) of the LRT layer in flight
     // identity of the draw currently held in the sampled-weight slab (set by forward, reused by the matching backward)
     const void* samp_mu = nullptr; const void* samp_rho = nullptr; const void* samp_ws = nullptr;
     uint64_t samp_seed = 0; uint32_t samp_step = 0, samp_k0 = 0; int samp_n = 0;
@@ -106,8 +110,9 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         if (d.out < 0 || d.out >= n_t || d.out == p.input) return fail("plan: op %d: bad output tensor", i);
         if (p.t[d.out].producer >= 0) return fail("plan: tensor %d produced twice", d.out);
         p.t[d.out].producer = i;
-        if (d.type == MFVI_OP_CONV) {
+        if (d.type == MFVI_OP_CONV || d.type == MFVI_OP_CONV_LRT) {
             if (d.in0 < 0 || d.in0 >= n_t) return fail("plan: op %d: bad input tensor", i);
+            if (d.type == MFVI_OP_CONV_LRT) { ++p.n_lrt; if (d.b_off < 0) return fail("plan: op %d: a local-reparameterisation layer needs its bias (skip() builds every conv with one)", i); }
             const TensorInfo& x = p.t[d.in0]; const TensorInfo& y = p.t[d.out];
             if (!(((d.ksize == 3 || d.ksize == 5) && (d.stride == 1 || d.stride == 2)) || (d.ksize == 1 && d.stride == 1)))
                 return fail("plan: op %d: conv ksize %d stride %d not supported (3x3 / 5x5 s1/s2, 1x1 s1)", i, d.ksize, d.stride);
@@ -144,13 +149,14 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
                 return fail("plan: op %d reads tensor %d before it is produced", i, ins[q]);
     }
     for (int i = 0; i < n_t; ++i) {
-        if (p.t[i].d.drop_p > 0.f && (p.t[i].producer < 0 || p.ops[p.t[i].producer].d.type != MFVI_OP_CONV))
+        if (p.t[i].d.drop_p > 0.f && (p.t[i].producer < 0 || p.ops[p.t[i].producer].d.type == MFVI_OP_CONCAT_UP))
             return fail("plan: tensor %d: Dropout2d must follow a convolution", i);
         if (i != p.input && p.t[i].producer < 0) return fail("plan: tensor %d is never produced", i);
         if (i != p.output && p.t[i].consumers.empty()) return fail("plan: tensor %d is never consumed", i);
         if (i == p.output && !p.t[i].consumers.empty()) return fail("plan: the output tensor has consumers");
         bool cat = false;
         for (int c : p.t[i].consumers) cat |= p.ops[c].d.type == MFVI_OP_CONCAT_UP;
+        if (p.n_lrt && p.t[i].d.drop_p > 0.f) return fail("plan: Dropout2d and local-reparameterisation layers are not combined by any runner");
         if (cat && p.t[i].consumers.size() != 1) return fail("plan: tensor %d feeds a concat and something else", i);
         if (p.t[i].consumers.size() > 2) return fail("plan: tensor %d has %d consumers (max 2)", i, (int)p.t[i].consumers.size());
     }
@@ -186,17 +192,29 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     }
     long long shared_scratch = 0;
     for (auto& o : p.ops)
-        if (o.d.type == MFVI_OP_CONV) {
+        if (o.d.type != MFVI_OP_CONCAT_UP) {
             const int P = o.g.ks / 2;
+            const bool lrt = o.d.type == MFVI_OP_CONV_LRT;
             const long long n = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P) * p.max_samples;
-            if (p.t[o.d.in0].consumers.size() > 1) o.scratch_off = take(n);       // lives until the fold of in0
-            else if (n > shared_scratch) shared_scratch = n;
+            if (p.t[o.d.in0].consumers.size() > 1) { o.scratch_off = take(n); if (lrt) o.scratch2_off = take(n); }       // live until the fold of in0
+            else if ((lrt ? 2 : 1) * n > shared_scratch) shared_scratch = (lrt ? 2 : 1) * n;
+            if (lrt) {
+                const long long no = (long long)o.g.Cout * o.g.Ho * o.g.Wo * p.max_samples;
+                o.s2_off = take(no);
+                if (no > p.lrt_tmp_n) p.lrt_tmp_n = no;
+            }
         }
     const long long shared_off = take(shared_scratch);
-    for (auto& o : p.ops) if (o.d.type == MFVI_OP_CONV && o.scratch_off < 0) o.scratch_off = shared_off;
+    for (auto& o : p.ops)
+        if (o.d.type != MFVI_OP_CONCAT_UP && o.scratch_off < 0) {
+            const int P = o.g.ks / 2;
+            o.scratch_off = shared_off;
+            if (o.d.type == MFVI_OP_CONV_LRT) o.scratch2_off = shared_off + (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P) * p.max_samples;
+        }
+    if (p.n_lrt) { p.sig2_off = take(p.n_vi); p.dsig2_off = take(p.n_vi); p.lrt_tmp_off = take(p.lrt_tmp_n); }
     // weights of the MFMA-served layers are sampled once per pass into [max_samples][n_vi]
     std::vector<SampleEntry> samp;
-    for (auto& o : p.ops)
+    for (auto& o : p.ops)      // (LRT layers draw nothing in weight space: their convolutions read mu and softplus(rho)^2)
         if (o.d.type == MFVI_OP_CONV && !(o.g.Cin & 3) && !(o.g.w_off & 3) && o.g.Cin <= MFVI_MAX_C && o.g.Cout <= MFVI_MAX_C) {
             SampleEntry e{};
             e.w_off = o.g.w_off; e.b_off = o.g.b_off; e.n_w = o.g.Cout * o.g.Cin * o.g.ks * o.g.ks; e.n_b = o.g.b_off >= 0 ? o.g.Cout : 0;
@@ -205,7 +223,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
             samp.push_back(e);
         }
     p.n_samp = (int)samp.size();
-    for (auto& o : p.ops) if (o.d.type == MFVI_OP_CONV) ++p.n_generic;
+    for (auto& o : p.ops) if (o.d.type != MFVI_OP_CONCAT_UP) ++p.n_generic;
     p.n_generic -= p.n_samp;
     if (p.n_generic > 0) p.p32_off = take(2 * p.n_vi);
     if (p.n_samp) {
@@ -217,7 +235,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     // partial-dW slabs: up to ~4M floats per layer, at least one pixel strip
     int n_conv = 0;
     for (auto& o : p.ops)
-        if (o.d.type == MFVI_OP_CONV) {
+        if (o.d.type != MFVI_OP_CONCAT_UP) {
             ++n_conv;
             const long long n_w = (long long)o.g.Cout * o.g.Cin * o.g.ks * o.g.ks;
             o.part_stride = n_w + (o.g.b_off >= 0 ? align_up(o.g.Cout, 4) : 0);
@@ -327,6 +345,38 @@ bool grad_from_slab()
     return on;
 }
 
+// conv2d(reflection_pad(view), w, b) with EXPLICIT float32 weights (w_base + g.w_off, bias at w_base + g.b_off), no sampling: the two
+// convolutions of a local-reparameterisation layer.  MFMA kernel when the shape is served, else the generic one (w = "mu", eval branch).
+int conv_fwd_plain(const TView& v, const ConvGeom& g, const float* w_base, OutDesc od, int n, hipStream_t st)
+{
+    int rc = use_mfma() ? launch_conv_fwd_mfma(v, g, w_base, 0, od, n, st) : -2;
+    if (rc == -2 || rc == -3) { RngKey none{}; rc = launch_conv_fwd(v, g, w_base, w_base, none, 0, od, n, st); }
+    return rc;
+}
+int conv_bwd_data_plain(const GView& gy, const ConvGeom& g, const float* w_base, float* dxp, long long per, int n, hipStream_t st)
+{
+    int rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, g, w_base, 0, dxp, per, n, st) : -2;
+    if (rc == -2 || rc == -3) { RngKey none{}; rc = launch_conv_bwd_data(gy, g, w_base, w_base, none, 0, dxp, per, n, st); }
+    return rc;
+}
+
+// Gradient wrt tensor `tid` once every consumer has written its padded input gradient: reflection-pad adjoint fold, sum over the
+// consumers (an LRT consumer contributes two sources, the variance branch with the factor 2 * view(x)), LeakyReLU', BN-backward sums.
+int fold_consumers(mfvi_plan* plan, const Ctx& c, int tid, const TView& xin, float* dz, int sample_weights, int op_index, int n_samples, hipStream_t st)
+{
+    const TensorInfo& x = plan->t[tid];
+    FoldSrc srcs[MAX_FOLD_SRC]; int ns = 0;
+    for (int ci : x.consumers) {
+        const OpInfo& co = plan->ops[ci]; const int Pc = co.g.ks / 2;
+        const long long per = (long long)co.g.Cin * (co.g.H + 2 * Pc) * (co.g.W + 2 * Pc);
+        srcs[ns++] = FoldSrc{c.farena() + co.scratch_off, per, Pc, 0};
+        if (co.d.type == MFVI_OP_CONV_LRT && sample_weights) srcs[ns++] = FoldSrc{c.farena() + co.scratch2_off, per, Pc, 1};
+    }
+    float* ga = (tid == plan->input) ? dz : c.farena() + x.ga_off;
+    ProfScope ps(plan, op_index, PASS_FINALIZE, st);
+    return launch_finalize_dx(srcs, ns, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
+}
+
 RngKey base_key(uint64_t seed, uint32_t step, uint32_t k0)
 {
     RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = 0; k.sample = k0; k.step = step; return k;
@@ -416,6 +466,11 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
+    if (plan->n_lrt && sample_weights) {      // weights of the variance convolutions of this pass
+        if (!rho) { set_error("forward: local-reparameterisation layers take float32 parameters"); return -1; }
+        const int rc = launch_lrt_sigma2(rho, plan->n_vi, c.farena() + plan->sig2_off, st);
+        if (rc) { set_error("forward: sigma^2 launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    }
     // MFMA-served layers: draw every weight once per (layer, sample); without sampling the kernels read mu (stride 0)
     // (bf16 parameters: the slab also serves w = mu, as one float32 copy shared by all samples)
     const bool presample = use_mfma() && (sample_weights || bf16) && plan->n_samp > 0;
@@ -440,7 +495,19 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         od.stats = y.d.has_bn ? c.fstats() + y.stats_off : nullptr;
         int rc;
         ProfScope ps(plan, (int)i, PASS_FWD, st);
-        if (o.d.type == MFVI_OP_CONV) {
+        if (o.d.type == MFVI_OP_CONV_LRT) {
+            // LRTLayer.forward (reparam_layers.py:59-72): act_mu = conv(v, mu, mu_b); training: + sqrt(1e-16 + conv(v^2, sigma^2, sigma_b^2)) * eps
+            if (!mu) { set_error("forward: local-reparameterisation layers take float32 parameters"); return -1; }
+            if (!sample_weights) rc = conv_fwd_plain(c.view(o.d.in0), o.g, mu, od, n_samples, st);
+            else {
+                OutDesc oa; oa.data = c.farena() + plan->lrt_tmp_off; oa.sstride = y.numel; oa.stats = nullptr;
+                OutDesc os; os.data = c.farena() + o.s2_off; os.sstride = y.numel; os.stats = nullptr;
+                TView v2 = c.view(o.d.in0); v2.act |= MFVI_ACT_SQUARE;
+                rc = conv_fwd_plain(c.view(o.d.in0), o.g, mu, oa, n_samples, st);
+                if (!rc) rc = conv_fwd_plain(v2, o.g, c.farena() + plan->sig2_off, os, n_samples, st);
+                if (!rc) rc = launch_lrt_combine(oa.data, os.data, y.numel, y.d.C, (long long)y.d.H * y.d.W, key, o.g.layer_id, od, n_samples, st);
+            }
+        } else if (o.d.type == MFVI_OP_CONV) {
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
             if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); return -1; }
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
@@ -471,6 +538,11 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
+    if (plan->n_lrt && sample_weights) {
+        if (!rho) { set_error("backward: local-reparameterisation layers take float32 parameters"); return -1; }
+        hipError_t e = hipMemsetAsync(c.farena() + plan->dsig2_off, 0, sizeof(float) * plan->n_vi, st);
+        if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
     // the weights of this pass: the slab still holds them when the preceding forward was this very pass (same parameter
     // buffers, counters, sample range and workspace); otherwise they are re-drawn from the same counters
     const bool presample = use_mfma() && (sample_weights || bf16) && plan->n_samp > 0;
@@ -508,6 +580,37 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) {
         const OpInfo& o = plan->ops[i];
         int rc = 0;
+        if (o.d.type == MFVI_OP_CONV_LRT) {
+            // autograd of LRTLayer.forward: d act_mu = dy, d act_var = dy * eps / (2 std); the two convolutions' weight gradients go to
+            // d mu and (through sigma^2 = softplus(rho)^2) to d rho; their input gradients meet in the fold, the variance branch with
+            // the factor 2 * view(x) of its x**2 operand.  Caller's stream throughout (an alternative estimator, not the hot path).
+            const GView gy = c.gview(o.d.out, dout);
+            const TView xin = c.view(o.d.in0);
+            const TensorInfo& x = plan->t[o.d.in0];
+            const TensorInfo& yt = plan->t[o.d.out];
+            const int P = o.g.ks / 2;
+            const long long per = (long long)o.g.Cin * (o.g.H + 2 * P) * (o.g.W + 2 * P);
+            const bool need_dx = (o.d.in0 != plan->input) || dz != nullptr;
+            if (!mu) { set_error("backward: local-reparameterisation layers take float32 parameters"); return -1; }
+            RngKey none{};
+            { ProfScope ps(plan, i, PASS_BWD_WEIGHT, st);
+              rc = launch_conv_bwd_weight(xin, gy, o.g, rho, none, 0, dmu, drho, n_samples, st); }          // d mu, d mu_b
+            if (!rc && need_dx) { ProfScope ps(plan, i, PASS_BWD_DATA, st);
+              rc = conv_bwd_data_plain(gy, o.g, mu, c.farena() + o.scratch_off, per, n_samples, st); }
+            if (!rc && sample_weights) {
+                float* ds2 = c.farena() + plan->lrt_tmp_off;
+                rc = launch_lrt_ds2(gy, c.farena() + o.s2_off, yt.numel, key, o.g.layer_id, ds2, n_samples, st);
+                GView g2{}; g2.ga = ds2; g2.gstride = yt.numel; g2.y = nullptr; g2.ystride = 0; g2.C = yt.d.C; g2.H = yt.d.H; g2.W = yt.d.W;
+                g2.stats = nullptr; g2.bsums = nullptr; g2.gamma = nullptr; g2.eps = 0.f; g2.drop = nullptr;
+                TView v2 = xin; v2.act |= MFVI_ACT_SQUARE;
+                float* dsig2 = c.farena() + plan->dsig2_off;
+                if (!rc) { ProfScope ps(plan, i, PASS_BWD_WEIGHT, st);
+                  rc = launch_conv_bwd_weight(v2, g2, o.g, rho, none, 0, dsig2, dsig2, n_samples, st); }    // d sigma^2 (weights and bias variance)
+                if (!rc && need_dx) { ProfScope ps(plan, i, PASS_BWD_DATA, st);
+                  rc = conv_bwd_data_plain(g2, o.g, c.farena() + plan->sig2_off, c.farena() + o.scratch2_off, per, n_samples, st); }
+            }
+            if (!rc && need_dx && x.consumers.front() == i) rc = fold_consumers(plan, c, o.d.in0, xin, dz, sample_weights, i, n_samples, st);
+        } else
         if (o.d.type == MFVI_OP_CONV) {
             const GView gy = c.gview(o.d.out, dout);
             const TView xin = c.view(o.d.in0);
@@ -556,18 +659,8 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                   rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, c.farena() + o.scratch_off, per, n_samples, st) : -2;
                   if ((rc == -2 || rc == -3) && !mu) { set_error("backward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table", i); rc = -1; }
                   if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
-                if (!rc && !folded && x.consumers.front() == i) {         // all consumers of in0 have run: fold + act' + BN sums
-                    FoldSrc srcs[2]; int ns = 0;
-                    for (int ci : x.consumers) {
-                        const OpInfo& co = plan->ops[ci]; const int Pc = co.g.ks / 2;
-                        srcs[ns].d = c.farena() + co.scratch_off;
-                        srcs[ns].sstride = (long long)co.g.Cin * (co.g.H + 2 * Pc) * (co.g.W + 2 * Pc);
-                        srcs[ns].pad = Pc; ++ns;
-                    }
-                    float* ga = (o.d.in0 == plan->input) ? dz : c.farena() + x.ga_off;
-                    ProfScope ps(plan, i, PASS_FINALIZE, st);
-                    rc = launch_finalize_dx(srcs, ns, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
-                }
+                if (!rc && !folded && x.consumers.front() == i)           // all consumers of in0 have run: fold + act' + BN sums
+                    rc = fold_consumers(plan, c, o.d.in0, xin, dz, sample_weights, i, n_samples, st);
             }
         } else {
             const GView gc = c.gview(o.d.out, dout);
@@ -609,6 +702,10 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho_v, key, sample_weights, n_samples, dmu, drho,
                                             presample && sample_weights && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu_v, st, bf16);
         if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    }
+    if (plan->n_lrt && sample_weights) {      // d rho += d sigma^2 * 2 softplus(rho) sigmoid(rho)
+        const int rc = launch_lrt_drho(c.farena() + plan->dsig2_off, rho, plan->n_vi, drho, st);
+        if (rc) { set_error("backward: lrt_drho launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     if (plan->n_entries) {
         const int rc = launch_bn_param_grads(plan->table_dev, plan->n_entries, plan->max_c, c.bsums(), n_samples, dbn, st);

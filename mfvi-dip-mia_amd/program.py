@@ -41,7 +41,8 @@ class Program:
             raise ValueError("dropout probability %r outside [0, 1)" % (p,))
         self.tensors[tid]["drop_p"] = float(p)
 
-    def conv(self, in_id, out_id, ksize, stride=1, bias=True):
+    def conv(self, in_id, out_id, ksize, stride=1, bias=True, lrt=False):
+        """Conv2dRT (default) or, with lrt=True, Conv2dLRT (local reparameterisation: BayTorch/modules/reparam_layers.py:39-72)."""
         cin, cout = self.tensors[in_id]["C"], self.tensors[out_id]["C"]
         w_off = self.n_vi
         self.n_vi += cout * cin * ksize * ksize
@@ -50,8 +51,8 @@ class Program:
             b_off = self.n_vi
             self.n_vi += cout
         lid = len(self.layers)
-        self.layers.append(dict(cin=cin, cout=cout, k=ksize, stride=stride, w_off=w_off, b_off=b_off))
-        self.ops.append(dict(type=L.OP_CONV, in0=in_id, in1=-1, out=out_id, ksize=ksize, stride=stride, layer_id=lid,
+        self.layers.append(dict(cin=cin, cout=cout, k=ksize, stride=stride, w_off=w_off, b_off=b_off, lrt=bool(lrt)))
+        self.ops.append(dict(type=L.OP_CONV_LRT if lrt else L.OP_CONV, in0=in_id, in1=-1, out=out_id, ksize=ksize, stride=stride, layer_id=lid,
                              up_mode=0, w_off=w_off, b_off=b_off))
         return lid
 
@@ -191,15 +192,18 @@ class Plan:
 
 
 def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(16, 32, 64, 128, 128), ns=(4, 4, 4, 4, 4),
-                 fd=3, fu=3, fs=1, need1x1_up=True, upsample_mode="bilinear", drop_down=0.0, drop_up=0.0):
+                 fd=3, fu=3, fs=1, need1x1_up=True, upsample_mode="bilinear", drop_down=0.0, drop_up=0.0, lrt=False):
     """The skip() hour-glass of the reference (models/skip.py:58-134) as a layer program, in module order:
     per scale  [skip-conv/BN/act], down-conv(s2)/BN/act, conv/BN/act, [deeper scale], Upsample, [Concat], BN,
     up-conv/BN/act, [1x1-conv/BN/act]; then the final 1x1 conv.  ns[i] == 0 drops the skip branch and its Concat
     (models/skip.py:62-66), need1x1_up / filter sizes / upsample_mode as in the inpainting runner
     (bayesian_optimization.py:2970-2998).  drop_down / drop_up > 0 put nn.Dropout2d(p) after the deeper / up convolutions
     (dropout_mode_down = dropout_mode_up = '2d' of the MC-dropout runners, bayesian_optimization.py:1526-1549).
+    lrt=True builds every convolution as a local-reparameterisation layer (MeanFieldVI(reparam='local')).
     Returns (program, input_id, output_id, tensor-id map)."""
     P = Program()
+    _conv = P.conv
+    P.conv = lambda *a, **kw: _conv(*a, lrt=lrt, **kw)
     names = {}
     zin = P.tensor(input_depth, H, W)
 
@@ -226,4 +230,5 @@ def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(1
 
     top = scale(0, zin)
     out = P.tensor(n_out, H, W); P.conv(top, out, 1, 1)
+    del P.conv
     return P, zin, out, names

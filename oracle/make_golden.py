@@ -638,6 +638,82 @@ def bookkeeping_raw(task, seed, i, img, C):
     return O.bookkeeping_raw(task, seed, i, img, C)
 
 
+def golden_lrt():
+    """Local reparameterisation: the reference's own Conv2dLRT layers (MeanFieldVI(reparam='local'),
+    BayTorch/modules/reparam_layers.py:39-72) with eps injected in OUTPUT space from RNG domain 7 (stream = layer, element j of
+    [Cout][Ho][Wo]): single layers forward / backward, and a 2-scale den net with K = 2."""
+    from models.common import conv as ref_conv
+    res = {}
+    cases = [(16, 4, 1, 1, 12, 12), (16, 16, 3, 2, 16, 16), (36, 16, 3, 1, 8, 8), (8, 12, 5, 1, 12, 16), (7, 5, 3, 1, 9, 11)]
+    for ci, (cin, cout, k, stride, H, W) in enumerate(cases):
+        seq = ref_conv(cin, cout, k, stride, bias=True, pad='reflection')
+        net = R["f2b"].MeanFieldVI(seq, prior={'mu': 0.0, 'sigma': 0.1}, replace_layers='all', reparam='local')
+        m = vi_layers(net)[0]
+        assert type(m).__name__ == "Conv2dLRT"
+        seed = 400 + ci
+        nw = cout * cin * k * k
+        mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.5 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+        with torch.no_grad():
+            m.W_mu.copy_(torch.from_numpy(mu[:nw].reshape(cout, cin, k, k))); m.W_rho.copy_(torch.from_numpy(rho[:nw].reshape(cout, cin, k, k)))
+            m.bias_mu.copy_(torch.from_numpy(mu[nw:])); m.bias_rho.copy_(torch.from_numpy(rho[nw:]))
+        x = torch.from_numpy(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(1, cin, H, W)).requires_grad_(True)
+        with EpsInjector() as inj:
+            Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+            inj.queue[:] = [torch.from_numpy(O.normal_fill(seed, 7, 0, 2, 5, cout * Ho * Wo).reshape(1, cout, Ho, Wo))]      # layer 0, sample 2, step 5
+            y = net(x)
+        dy = torch.from_numpy(O.normal_fill(seed, 2, 3, 0, 0, y.numel()).reshape(y.shape))
+        y.backward(dy)
+        res[f"case{ci}_shape"] = np.array([cin, cout, k, stride, H, W])
+        res[f"case{ci}_y"] = y.detach().numpy()[0]; res[f"case{ci}_dx"] = x.grad.numpy()[0]
+        res[f"case{ci}_dmu"] = np.concatenate([m.W_mu.grad.numpy().ravel(), m.bias_mu.grad.numpy()])
+        res[f"case{ci}_drho"] = np.concatenate([m.W_rho.grad.numpy().ravel(), m.bias_rho.grad.numpy()])
+        net.eval()
+        with torch.no_grad():
+            res[f"case{ci}_y_eval"] = net(x).numpy()[0]
+    res["n_cases"] = len(cases)
+    # 2-scale den net, K = 2, reference loop (gaussian_nll + temp * kl)
+    onet = O.make_net(32, 32, input_depth=8, n_out=2, nd=(8, 16), nu=(8, 16), ns=(4, 4))
+    temp = DEN["temp"]; prior_raw = float(np.sqrt(temp) * DEN["sigma"])
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    seed, K, step = 25, 2, 3
+    mu, rho, bnp = test_params(onet, seed)
+    n = onet.n_scales
+    net = R["mskip"].skip(onet.input_depth, onet.n_out, num_channels_down=[onet.nd[i] for i in range(n)], num_channels_up=[onet.nu[i] for i in range(n)],
+                          num_channels_skip=[onet.ns[i] for i in range(n)], upsample_mode='bilinear', downsample_mode='stride', need_sigmoid=False,
+                          need_bias=True, pad='reflection', act_fun='LeakyReLU', dropout_mode_down='None', dropout_mode_up='None',
+                          dropout_mode_skip='None', dropout_mode_output='None')
+    net = R["f2b"].MeanFieldVI(net, prior={'mu': 0.0, 'sigma': prior_raw}, replace_layers='all', reparam='local')
+    load_flat(net, mu, rho, bnp, conv, bn)
+    layers = vi_layers(net)
+    H = W = 32
+    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, onet.input_depth * H * W)).reshape(1, onet.input_depth, H, W)
+    tgt = torch.from_numpy(O.noisy(O.phantom(H, W, seed), 0.1, seed))[None, None]
+    # output sizes of the layers in call order (conv table: cin, cout, k, stride, w_off, b_off) — recorded by a dry forward
+    shapes = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: shapes.append(tuple(out.shape))) for m in layers]
+    net.eval()
+    with torch.no_grad():
+        net(torch.from_numpy(z))
+    for h in hooks:
+        h.remove()
+    net.train(); net.zero_grad()
+    outs = []; nll_sum = 0.0
+    with EpsInjector() as inj:
+        for kk in range(K):
+            inj.queue[:] = [torch.from_numpy(O.normal_fill(seed, 7, lid, kk, step, int(np.prod(sh))).reshape(sh)) for lid, sh in enumerate(shapes)]
+            out = net(torch.from_numpy(z))
+            nll = R["bu"].gaussian_nll(out[:, :1], out[:, 1:], tgt)
+            (nll / K).backward(); nll_sum += float(nll) / K
+            outs.append(out.detach().numpy()[0].copy())
+        kl = net.kl(); (temp * kl).backward()
+    dmu, drho, dbn = flat_grads(net, conv, bn, n_vi, n_bnp)
+    res.update(net_seed=seed, net_K=K, net_step=step, net_temp=temp, net_prior_sigma=np.float32(prior_raw + 1e-6), net_out=np.stack(outs), net_nll=nll_sum,
+               net_kl=float(kl), net_dmu=dmu, net_drho=drho, net_dbn=dbn,
+               net_layer_types=np.array([type(m).__name__ for m in layers]), net_keys=np.array(list(net.state_dict().keys())))
+    np.savez_compressed(os.path.join(GOLD, "lrt.npz"), **res)
+    print("lrt ok: net nll", nll_sum, "kl", float(kl), "|dmu|", np.linalg.norm(dmu), "|drho|", np.linalg.norm(drho))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if "--fullsize" in sys.argv:        # BASELINE configs 2-4 at 256^2 (strided) + the bf16-parameter twin of the 128^2 den net
@@ -646,6 +722,8 @@ if __name__ == "__main__":
         golden_net("full_ct_256_k1", O.make_net(256, 256, n_out=1), seed=1, K=1, task="ct", full_arrays=False, compact=True)
         golden_net("full_den_128_k1_bf16", O.make_net(128, 128), seed=1, K=1, task="den", full_arrays=False, bf16=True)
         sys.exit(0)
+    if "--lrt" in sys.argv:
+        golden_lrt(); sys.exit(0)
     if "--bookkeeping" in sys.argv:
         golden_bookkeeping(); sys.exit(0)
     if "--inp-dip" in sys.argv:
@@ -668,3 +746,4 @@ if __name__ == "__main__":
     golden_siblings()
     golden_inp_dip_loss()
     golden_bookkeeping()
+    golden_lrt()

@@ -505,3 +505,30 @@ def adam_bf16_sr(p_bits, g, m, v, lr, t, seed, stream):
     """In place: Adam in float32 + stochastic rounding to bf16 (the build's update rule for bf16 mu / rho); p_bits uint16, g / m / v float32."""
     assert p_bits.dtype == np.uint16 and p_bits.flags.c_contiguous
     lib().oracle_adam_bf16_sr(_p(p_bits), _p(g), _p(m), _p(v), C.c_long(p_bits.size), C.c_float(lr), C.c_int(t), C.c_uint64(seed), C.c_uint32(stream))
+
+
+# ---- local reparameterisation (Conv2dLRT) on the oracle's conv primitives ----------------------
+def lrt_eps(seed, step, sample, layer, n):
+    """eps of an LRT layer in OUTPUT space: element j of [Cout][Ho][Wo] (RNG domain 7, stream = layer)."""
+    return normal_fill(seed, 7, layer, sample, step, n)
+
+
+def lrt_conv(x, w_mu, w_rho, b_mu, b_rho, eps, stride, dy=None):
+    """LRTLayer.forward with layer_fn = conv2d behind ReflectionPad2d(k // 2) (BayTorch/modules/reparam_layers.py:59-72,
+    models/common.py:100-135) and its autograd:  y = conv(x, mu, b_mu) + sqrt(1e-16 + conv(x^2, softplus(rho)^2, softplus(b_rho)^2)) * eps.
+    Returns y, or (y, dx, dw_mu, dw_rho, db_mu, db_rho) when dy is given."""
+    x = _f(x); w_mu = _f(w_mu); w_rho = _f(w_rho); b_mu = _f(b_mu); b_rho = _f(b_rho); eps = _f(eps)
+    sw = softplus(w_rho.ravel()).reshape(w_rho.shape); sb = softplus(b_rho)
+    a = conv_fwd(x, w_mu, b_mu, stride)
+    s2 = conv_fwd(x * x, sw * sw, sb * sb, stride)
+    std = np.sqrt(np.float32(1e-16) + s2)
+    y = a + std * eps.reshape(a.shape)
+    if dy is None:
+        return y
+    dy = _f(dy)
+    ds2 = dy * eps.reshape(a.shape) / (2.0 * std)
+    dxa, dwm, dbm = conv_bwd(x, w_mu, stride, dy)
+    dxb, dws, dbs = conv_bwd(x * x, sw * sw, stride, ds2)
+    dx = dxa + 2.0 * x * dxb
+    sg = lambda r: 1.0 / (1.0 + np.exp(-r.astype(np.float64)))
+    return y, dx, dwm, dws * 2.0 * sw * sg(w_rho), dbm, dbs * 2.0 * sb * sg(b_rho)

@@ -114,8 +114,6 @@ def test_k_samples_in_one_call_and_errors(M):
     with pytest.raises(RuntimeError, match="no longer the latest"):
         o1.sum().backward()
     with pytest.raises(NotImplementedError):
-        M.MeanFieldVI(mk(), device=device)                      # constructor default reparam='local' (LRT) is not built
-    with pytest.raises(NotImplementedError):
         M.MeanFieldVI(mk(), device=torch.device('cpu'), reparam='')
     with pytest.raises(NotImplementedError):
         M.MeanFieldVI(mk(), prior={'mu': 0, 'sigma': 0.1, 'pi': 0.5}, device=device, reparam='')

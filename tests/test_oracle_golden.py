@@ -344,3 +344,22 @@ def test_bookkeeping(golden_dir, task):
             if task != "ct":
                 assert relerr(ale, g["%s_ale%d" % (task, i)]) < 1e-6
     assert relerr(bk.ema, g[task + "_ema"]) < 1e-6
+
+
+def test_lrt_layers(golden_dir):
+    """The oracle's Conv2dLRT (local reparameterisation in activation space, oracle.lrt_conv) against the reference's own layer."""
+    g = load(golden_dir, "lrt")
+    for ci in range(int(g["n_cases"])):
+        cin, cout, k, stride, H, W = [int(v) for v in g[f"case{ci}_shape"]]
+        seed = 400 + ci
+        nw = cout * cin * k * k
+        mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.5 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+        x = O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W)
+        yg = g[f"case{ci}_y"]
+        eps = O.lrt_eps(seed, 5, 2, 0, yg.size)
+        dy = O.normal_fill(seed, 2, 3, 0, 0, yg.size).reshape(yg.shape)
+        y, dx, dwm, dwr, dbm, dbr = O.lrt_conv(x, mu[:nw].reshape(cout, cin, k, k), rho[:nw].reshape(cout, cin, k, k), mu[nw:], rho[nw:], eps, stride, dy)
+        assert relerr(y, yg) < RTOL and relerr(dx, g[f"case{ci}_dx"]) < RTOL, ci
+        assert relerr(np.r_[dwm.ravel(), dbm], g[f"case{ci}_dmu"]) < RTOL and relerr(np.r_[dwr.ravel(), dbr], g[f"case{ci}_drho"]) < 5e-5, ci
+        assert relerr(O.conv_fwd(x, mu[:nw].reshape(cout, cin, k, k), mu[nw:], stride), g[f"case{ci}_y_eval"]) < RTOL
+    assert set(g["net_layer_types"]) == {"Conv2dLRT"}
