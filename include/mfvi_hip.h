@@ -84,6 +84,14 @@ int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled);
 /* Dropout2d layers of the program are active by default (the reference keeps its MC-dropout nets in train mode);
  * enabled = 0 makes them the identity (nn.Dropout2d in eval mode). */
 int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled);
+/* nn.BatchNorm2d's running statistics (models/common.py:96-97: momentum 0.1, unbiased variance; the reference never reads them, but they
+ * are part of the state_dict a reference run produces).  `running`: n_bn floats laid out like the BN block — running_mean at the gamma
+ * slots, running_var at the beta slots.  mfvi_plan_bn_update_running applies the update of the n_samples batch-1 forwards just run by
+ * mfvi_forward (their batch sums are still in the workspace), sample by sample in order.  mfvi_plan_set_bn_eval(plan, running) makes
+ * mfvi_forward normalise with these statistics instead (module.eval(); NULL: back to batch statistics); forward only — mfvi_backward
+ * refuses while it is set.  The pointer is kept, the caller keeps the buffer alive. */
+int mfvi_plan_bn_update_running(const mfvi_plan* plan, const void* workspace, int n_samples, float momentum, float* running, void* stream);
+int mfvi_plan_set_bn_eval(mfvi_plan* plan, const float* running);
 /* bfloat16 storage of mu / rho (BASELINE configs[4]: "bf16 mu/rho with fp32 KL accumulate"; the reference keeps float32 Parameters:
  * BayTorch/modules/module.py:45-62).  With MFVI_PARAM_BF16 the `mu` / `rho` arguments of mfvi_forward / mfvi_backward / mfvi_plan_autotune
  * point to arrays of n_vi bf16 values (uint16_t: the upper half of the float32 pattern); the reparameterisation draw reads them directly

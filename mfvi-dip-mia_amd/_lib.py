@@ -35,6 +35,8 @@ SIGNATURES = {
     "mfvi_plan_workspace_bytes": (_I64, [_P]),
     "mfvi_plan_set_dropout": (_I, [_P, _I]),
     "mfvi_plan_set_param_dtype": (_I, [_P, _I]),
+    "mfvi_plan_bn_update_running": (_I, [_P, _P, _I, _F, _P, _P]),
+    "mfvi_plan_set_bn_eval": (_I, [_P, _P]),
     "mfvi_plan_set_side_stream": (_I, [_P, _I]),
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
     "mfvi_backward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -158,11 +158,29 @@ class MeanFieldVI(nn.Module):
             b.to(self.device)                                  # running stats buffers
             b.weight.data = bn[off:off + c]; b.bias.data = bn[off + c:off + 2 * c]
             off += 2 * c
+        self._bind_running()
         self._param_list = []
         for m in self._vi:
             self._param_list += [m.W_mu, m.W_rho] + ([m.bias_mu, m.bias_rho] if m._has_bias else [])
         for b in self._bn:
             self._param_list += [b.weight, b.bias]
+
+    def _bind_running(self):
+        """running_mean / running_var of every BatchNorm2d become views of ONE flat buffer laid out like the BN block (mean at the gamma
+        slots, variance at the beta slots), which mfvi_plan_bn_update_running / mfvi_plan_set_bn_eval take (models/common.py:96-97)."""
+        run = torch.zeros(max(self.n_bn, 1), dtype=torch.float32, device=self.device)
+        for b in self._bn:
+            c, off = b.num_features, b._bn_off
+            if b.track_running_stats:
+                run[off:off + c] = b.running_mean.to(run); run[off + c:off + 2 * c] = b.running_var.to(run)
+                b.running_mean = run[off:off + c]; b.running_var = run[off + c:off + 2 * c]
+                b.num_batches_tracked = b.num_batches_tracked.to(self.device)
+        self._running = run
+
+    def _running_intact(self):
+        base = self._running.data_ptr()
+        return all((not b.track_running_stats) or (b.running_mean.data_ptr() == base + 4 * b._bn_off and b.running_var.data_ptr() == base + 4 * (b._bn_off + b.num_features))
+                   for b in self._bn)
 
     def _views_intact(self):
         base = self._flat.data_ptr()
@@ -311,9 +329,9 @@ class MeanFieldVI(nn.Module):
 
     # ------------------------------------------------------------------ nn.Module surface
     def forward(self, x):
-        if not all(b.training for b in self._bn):
-            raise NotImplementedError("BatchNorm in eval mode (running statistics) is not built: the reference never calls .eval() on "
-                                      "these nets.  For a deterministic pass keep .train() and call set_sampling(False) (w = mu).")
+        modes = {b.training for b in self._bn}
+        if len(modes) > 1:
+            raise NotImplementedError("BatchNorm layers in mixed train / eval mode")
         return _NetFunction.apply(self, x, *self._param_list)
 
     def set_sampling(self, enabled=True):
@@ -352,7 +370,22 @@ class MeanFieldVI(nn.Module):
         dropping = any(d.training for d in self._drops)      # nn.Dropout2d is the identity in eval mode
         if self._drops:
             L.check(L.lib().mfvi_plan_set_dropout(plan.handle, int(dropping)))
+        if self._bn and not self._running_intact():
+            self._bind_running()
+        bn_eval = bool(self._bn) and not self._bn[0].training
+        if bn_eval and not all(b.track_running_stats for b in self._bn):
+            raise NotImplementedError("BatchNorm2d(track_running_stats=False) in eval mode")
+        # module.eval(): running statistics instead of batch statistics (forward only; the reference never trains in eval mode)
+        L.check(L.lib().mfvi_plan_set_bn_eval(plan.handle, L.ptr(self._running) if bn_eval else None))
         out = plan.forward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, sample)
+        if self._bn and not bn_eval and all(b.track_running_stats for b in self._bn):
+            # the running statistics a reference run leaves in its state_dict: one update per batch-1 forward, sample by sample
+            mom = {b.momentum for b in self._bn}
+            if len(mom) != 1 or None in mom:
+                raise NotImplementedError("BatchNorm2d momentum must be one number for all layers (the skip() nets use the default 0.1)")
+            L.check(L.lib().mfvi_plan_bn_update_running(plan.handle, L.ptr(plan.workspace), self.n_samples, float(mom.pop()), L.ptr(self._running), L.stream_ptr()))
+            for b in self._bn:
+                b.num_batches_tracked += self.n_samples
         self._token += 1
         if sample or dropping:
             self._step += 1                  # fresh eps / dropout masks for every call, like randn_like in VIModule.rsample
@@ -465,6 +498,7 @@ class FusedNet(MeanFieldVI):
                 raise NotImplementedError("non-affine BatchNorm")
             b.to(self.device)
             self._rebind_bn(flat, b)
+        self._bind_running()
         self._param_list = []
         for m in self._vi:
             self._param_list += [m.weight] + ([m.bias] if m._has_bias else [])

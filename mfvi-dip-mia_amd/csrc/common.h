@@ -359,6 +359,10 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
 // Dropout2d factors of one forward: arena[e.drop_off + k*C + c] for every entry, sample k, channel c (RNG domain 5, stream layer_id)
 struct DropEntry { long long drop_off; int C, layer_id; float p; int pad; };
 int launch_dropout_masks(const DropEntry* table_dev, int n_entries, RngKey key, int n_samples, float* arena, hipStream_t st);
-struct BnGradEntry { long long bsums_off; long long bn_off; int C; int pad; };
+struct BnGradEntry { long long bsums_off; long long bn_off; int C; int hw; };      // hw = H * W of the normalised tensor
+// nn.BatchNorm2d's running statistics after n_samples training forwards (batch sums in fstats), and their use in eval mode
+int launch_bn_update_running(const BnGradEntry* table_dev, int n_entries, int max_c, const double* fstats_base, int n_samples, float momentum,
+                             float* running, hipStream_t st);
+int launch_bn_eval_fill(const BnGradEntry* table_dev, int n_entries, int max_c, double* fstats_base, int n_samples, const float* running, hipStream_t st);
 int launch_bn_param_grads(const BnGradEntry* table_dev, int n_entries, int max_c, const double* bsums_base, int n_samples,
                           float* dbn, hipStream_t st);

@@ -423,6 +423,42 @@ __global__ void bn_param_grads_kernel(const BnGradEntry* __restrict__ table, con
     }
 }
 
+// nn.BatchNorm2d(momentum = 0.1) in training mode (models/common.py:96-97) after each of the n_samples batch-1 forwards, in order:
+//   running_mean = (1 - m) running_mean + m mean_k;  running_var = (1 - m) running_var + m var_k * n / (n - 1)   (unbiased, n = H * W)
+// running is laid out like the BN block: mean at the gamma slots, variance at the beta slots.
+__global__ void bn_update_running_kernel(const BnGradEntry* __restrict__ table, const double* __restrict__ fstats, int n_samples, float momentum,
+                                         float* __restrict__ running)
+{
+    const BnGradEntry e = table[blockIdx.x];
+    const double n = (double)e.hw;
+    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+        float rm = running[e.bn_off + c], rv = running[e.bn_off + e.C + c];
+        for (int k = 0; k < n_samples; ++k) {
+            const double* s = fstats + e.bsums_off + ((long long)k * e.C + c) * 2;
+            const double m = s[0] / n;
+            double var = s[1] / n - m * m; if (var < 0) var = 0;
+            const float unb = (float)(n > 1 ? var * n / (n - 1) : var);
+            rm = (1.f - momentum) * rm + momentum * (float)m;
+            rv = (1.f - momentum) * rv + momentum * unb;
+        }
+        running[e.bn_off + c] = rm; running[e.bn_off + e.C + c] = rv;
+    }
+}
+// eval mode: the consumers form their channel constants from (sum, sum of squares); write the pair that reproduces mean = running_mean,
+// biased variance = running_var for every sample, and let no producer add to it
+__global__ void bn_eval_fill_kernel(const BnGradEntry* __restrict__ table, double* __restrict__ fstats, int n_samples, const float* __restrict__ running)
+{
+    const BnGradEntry e = table[blockIdx.x];
+    const double n = (double)e.hw;
+    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+        const double rm = running[e.bn_off + c], rv = running[e.bn_off + e.C + c];
+        for (int k = 0; k < n_samples; ++k) {
+            double* s = fstats + e.bsums_off + ((long long)k * e.C + c) * 2;
+            s[0] = rm * n; s[1] = (rv + rm * rm) * n;
+        }
+    }
+}
+
 // ---- local reparameterisation (BayTorch/modules/reparam_layers.py:59-72) ---------------------------------------------------
 __global__ __launch_bounds__(256) void lrt_sigma2_kernel(const float* __restrict__ rho, long long n, float* __restrict__ sig2)
 {
@@ -575,6 +611,23 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
     TView av = a ? *a : b;
     hipLaunchKernelGGL(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
                        ga_b_sstride, bsums_b, tiles_x, nearest);
+    return (int)hipGetLastError();
+}
+
+int launch_bn_update_running(const BnGradEntry* table_dev, int n_entries, int max_c, const double* fstats_base, int n_samples, float momentum,
+                             float* running, hipStream_t st)
+{
+    if (n_entries == 0) return 0;
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3(n_entries), dim3(max_c < 64 ? 64 : (max_c > 256 ? 256 : ((max_c + 63) / 64) * 64)), 0, st,
+                       table_dev, fstats_base, n_samples, momentum, running);
+    return (int)hipGetLastError();
+}
+
+int launch_bn_eval_fill(const BnGradEntry* table_dev, int n_entries, int max_c, double* fstats_base, int n_samples, const float* running, hipStream_t st)
+{
+    if (n_entries == 0) return 0;
+    hipLaunchKernelGGL(bn_eval_fill_kernel, dim3(n_entries), dim3(max_c < 64 ? 64 : (max_c > 256 ? 256 : ((max_c + 63) / 64) * 64)), 0, st,
+                       table_dev, fstats_base, n_samples, running);
     return (int)hipGetLastError();
 }
 

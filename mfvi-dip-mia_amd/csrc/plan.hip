@@ -58,6 +58,7 @@ struct mfvi_plan {
     int param_dtype = MFVI_PARAM_F32;          // storage of mu / rho handed to forward / backward (MFVI_PARAM_BF16: bf16_t arrays)
     int n_generic = 0;                         // conv layers outside the sampling table (served by the generic fp32 kernels)
     long long p32_off = -1;                    // floats: [mu | rho] expanded to float32 for those kernels when mu / rho are bf16
+    const float* bn_eval = nullptr;            // BatchNorm in eval mode: running statistics used by mfvi_forward (nullptr: batch statistics)
     int n_lrt = 0;                             // local-reparameterisation layers
     long long sig2_off = -1, dsig2_off = -1;   // floats [n_vi] each: softplus(rho)^2 of this pass / gradient wrt it
     long long lrt_tmp_off = -1, lrt_tmp_n = 0; // floats: mean-convolution output (forward) / ds2 (backward) of the LRT layer in flight
@@ -166,7 +167,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     for (int i = 0; i < n_t; ++i)
         if (p.t[i].d.has_bn) {
             p.t[i].stats_off = sd; sd += (long long)p.max_samples * p.t[i].d.C * 2;
-            BnGradEntry e; e.bsums_off = p.t[i].stats_off; e.bn_off = p.t[i].d.bn_off; e.C = p.t[i].d.C; e.pad = 0;
+            BnGradEntry e; e.bsums_off = p.t[i].stats_off; e.bn_off = p.t[i].d.bn_off; e.C = p.t[i].d.C; e.hw = p.t[i].d.H * p.t[i].d.W;
             table.push_back(e); if (p.t[i].d.C > p.max_c) p.max_c = p.t[i].d.C;
         }
     p.stats_doubles = align_up(sd, 32);
@@ -428,6 +429,23 @@ int mfvi_plan_set_param_dtype(mfvi_plan* plan, int dtype)
     return 0;
 }
 
+int mfvi_plan_set_bn_eval(mfvi_plan* plan, const float* running)
+{
+    if (!plan) { set_error("set_bn_eval: null plan"); return -1; }
+    plan->bn_eval = running;
+    return 0;
+}
+
+int mfvi_plan_bn_update_running(const mfvi_plan* plan, const void* workspace, int n_samples, float momentum, float* running, void* stream)
+{
+    if (!plan || !workspace || !running || n_samples < 1 || n_samples > plan->max_samples || !(momentum >= 0.f && momentum <= 1.f)) {
+        set_error("bn_update_running: bad arguments"); return -1; }
+    if (plan->bn_eval) { set_error("bn_update_running: the plan is in BatchNorm eval mode (no batch statistics were formed)"); return -1; }
+    const int rc = launch_bn_update_running(plan->table_dev, plan->n_entries, plan->max_c, (const double*)workspace, n_samples, momentum, running, (hipStream_t)stream);
+    if (rc) set_error("bn_update_running: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
 int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled)
 {
     if (!plan) { set_error("set_dropout: null plan"); return -1; }
@@ -466,6 +484,10 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     const RngKey key = base_key(seed, step, k0);
+    if (plan->bn_eval && plan->n_entries) {   // nn.BatchNorm2d in eval mode: the running statistics stand in for every sample's batch sums
+        const int rc = launch_bn_eval_fill(plan->table_dev, plan->n_entries, plan->max_c, c.fstats(), n_samples, plan->bn_eval, st);
+        if (rc) { set_error("forward: bn_eval_fill launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    }
     if (plan->n_lrt && sample_weights) {      // weights of the variance convolutions of this pass
         if (!rho) { set_error("forward: local-reparameterisation layers take float32 parameters"); return -1; }
         const int rc = launch_lrt_sigma2(rho, plan->n_vi, c.farena() + plan->sig2_off, st);
@@ -492,7 +514,7 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         const TensorInfo& y = plan->t[o.d.out];
         OutDesc od;
         od.data = (o.d.out == plan->output) ? out : c.farena() + y.act_off; od.sstride = y.numel;
-        od.stats = y.d.has_bn ? c.fstats() + y.stats_off : nullptr;
+        od.stats = (y.d.has_bn && !plan->bn_eval) ? c.fstats() + y.stats_off : nullptr;
         int rc;
         ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV_LRT) {
@@ -529,6 +551,7 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     hipStream_t st = (hipStream_t)stream;
     Ctx c{*plan, (char*)workspace, bn, z, n_samples};
     const bool bf16 = plan->param_dtype == MFVI_PARAM_BF16;
+    if (plan->bn_eval) { set_error("backward: BatchNorm is in eval mode (mfvi_plan_set_bn_eval); the kernels implement the training-mode backward only"); return -1; }
     if (bf16 && !use_mfma()) { set_error("backward: bf16 parameters need the MFMA path (MFVI_DISABLE_MFMA is set)"); return -1; }
     if (bf16 && (((uintptr_t)mu_v | (uintptr_t)rho_v) & 7)) { set_error("backward: bf16 mu / rho must be 8-byte aligned"); return -1; }
     const float* mu = nullptr; const float* rho = nullptr;

@@ -19,6 +19,7 @@ import time
 import numpy as np
 
 from . import _lib as L
+from . import artifacts as A
 from .engine import ElboEngine, SiblingEngine
 
 MC_ITER = 25            # ring-buffer length (bayesian_optimization.py:1314)
@@ -236,26 +237,24 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
             if verbose:
                 nll, kl, loss = eng.losses()
                 print("iter %6d  loss %.5f  nll %.5f  kl %.4e  (%.1f it/s)" % (i, loss, nll, kl, (i + 1) / (time.perf_counter() - t0)))
+            if plot and save:                                        # loss_<method>.png, out_avg.png, out_var.png, out_ale.png (:1418-1422)
+                mn, mg, ps_, _ = book.results()
+                A.snapshot_pngs(run_dir, method, i, mn, mg, ps_, recon[None], None if method == "dip" else var[None],
+                                None if (method == "dip" or task == "ct") else ale[None])
     torch.cuda.synchronize()
     mse_noisy, mse_gt, psnrs, ssims = book.results()
     if save:
-        wrap = lambda a: {method: a}                                  # MSE_CORRUPTED['mfvi'] / ['dip'] / ['mcd'] / ['sgld'] of the reference
-        unc = (lambda a: {}) if method == "dip" else wrap            # run_*_dip leaves UNCERTS_EPI / UNCERTS_ALE empty (:1126-1127, :1230-1232)
         # first two keys as the reference writes them per task: den img_gt / img_noisy (:1438), sr img_hr / img_lr (:2258), ct img_gt / img_radon (:643)
         # with the reference's shapes: get_image() arrays are (1, H, W), img_lr is squeezed, the CT tensors keep (1, 1, ., .)
-        head = dict(den=dict(img_gt=img_np[None], img_noisy=None if noisy is None else noisy[None]), sr=dict(img_hr=img_np[None], img_lr=extra.get("img_lr")),
-                    ct=dict(img_gt=img_np[None, None], img_radon=extra.get("img_radon")))[task]
-        np.savez(os.path.join(run_dir, "save.npz"), **head,
-                 mse_noisy=wrap(mse_noisy), mse_gt=wrap(mse_gt), recons=wrap(recons), uncerts=unc(uncerts_epi), uncerts_ale=unc(uncerts_ale),
-                 psnrs=wrap(psnrs), ssims=wrap(ssims))
+        head = dict(den=(img_np[None], None if noisy is None else noisy[None]), sr=(img_np[None], extra.get("img_lr")),
+                    ct=(img_np[None, None], extra.get("img_radon")))[task]
+        A.save_npz(run_dir, task, method, head, mse_noisy, mse_gt, recons, uncerts_epi, uncerts_ale, psnrs, ssims)
         with open(os.path.join(run_dir, "locals.txt"), "a") as f:
             print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
-        if plot:
-            try:
-                from PIL import Image
-                Image.fromarray((np.clip(recons[-1, 0], 0, 1) * 255).astype(np.uint8)).save(os.path.join(run_dir, "out_avg.png"))
-            except Exception:
-                pass
+            if plot:                                                  # mse_noisy / mse_gt / psnrs / ssims .png + the maxima lines (:201-258, :1431-1433)
+                A.plot_results({method: mse_noisy}, {method: mse_gt}, {method: psnrs}, {method: ssims}, run_dir, f)
+        if plot and task == "sr":
+            A.sr_input_png(run_dir, img_np[None], extra["img_lr"], factor)
     return dict(psnr=float(psnrs[-1, 2]), run_dir=run_dir if save else None, psnrs=psnrs, ssims=ssims, mse_noisy=mse_noisy, mse_gt=mse_gt,
                 recons=recons, uncerts=uncerts_epi, uncerts_ale=uncerts_ale, seconds=time.perf_counter() - t0, engine=eng)
 
@@ -361,18 +360,14 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
     torch.cuda.synchronize()
     mse_corrupted, mse_gt, psnrs, ssims = book.results()
     if save:
-        wrap = lambda a: {method: a}
-        unc = (lambda a: {}) if method == "dip" else wrap            # run_inp_dip leaves UNCERTS_EPI / UNCERTS_ALE empty (:2884-2886)
-        np.savez(os.path.join(run_dir, "save.npz"), img_inpainting=img_np, img_mask=mask_np, mse_corrupted=wrap(mse_corrupted), mse_gt=wrap(mse_gt),
-                 recons=wrap(recons), uncerts=unc(uncerts_epi), uncerts_ale=unc(uncerts_ale), psnrs=wrap(psnrs), ssims=wrap(ssims))
+        A.save_npz(run_dir, "inp", method, (img_np, mask_np), mse_corrupted, mse_gt, recons, uncerts_epi, uncerts_ale, psnrs, ssims)
         with open(os.path.join(run_dir, "locals.txt"), "a") as f:
             print("max psnr_gt_sm = %.4f, max ssim_gt_sm = %.4f" % (np.nanmax(psnrs[:, 2]), np.nanmax(ssims[:, 2])), file=f)
+            if plot:
+                A.plot_results({method: mse_corrupted}, {method: mse_gt}, {method: psnrs}, {method: ssims}, run_dir, f)
         if plot:
-            try:
-                from PIL import Image
-                Image.fromarray((np.clip(recons[-1].transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)).save(os.path.join(run_dir, "out_avg.png"))
-            except Exception:
-                pass
+            A.snapshot_pngs(run_dir, method, num_iter - 1, mse_corrupted, mse_gt, psnrs, recons[-1], None if method == "dip" else uncerts_epi[-1],
+                            None if method == "dip" else uncerts_ale[-1])
     return dict(psnr=float(psnrs[-1, 2]), run_dir=run_dir if save else None, psnrs=psnrs, ssims=ssims, mse_corrupted=mse_corrupted, mse_gt=mse_gt,
                 recons=recons, uncerts=uncerts_epi, uncerts_ale=uncerts_ale, seconds=time.perf_counter() - t0, engine=eng)
 

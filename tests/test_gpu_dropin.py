@@ -117,8 +117,48 @@ def test_k_samples_in_one_call_and_errors(M):
         M.MeanFieldVI(mk(), device=torch.device('cpu'), reparam='')
     with pytest.raises(NotImplementedError):
         M.MeanFieldVI(mk(), prior={'mu': 0, 'sigma': 0.1, 'pi': 0.5}, device=device, reparam='')
-    with pytest.raises(NotImplementedError):
-        net.eval(); net(x)
+
+
+def test_batchnorm_running_statistics_and_eval_mode(M):
+    """nn.BatchNorm2d as the reference's nets carry it (models/common.py:96-97): training forwards update running_mean / running_var with
+    momentum 0.1 and the unbiased variance, one update per batch-1 forward (n_samples of them per call), num_batches_tracked counts them,
+    and .eval() normalises with those statistics and w = mu — all compared with the same net executed by plain torch modules."""
+    import copy
+    import torch.nn.functional as F
+    device = torch.device('cuda')
+    torch.manual_seed(0)
+    mk = lambda: M.get_net(8, 'skip', 'reflection', skip_n33d=[8, 16], skip_n33u=[8, 16], skip_n11=4, num_scales=2, n_channels=2, upsample_mode='bilinear')
+    plain = mk().to(device)                                              # torch executes this copy (deterministic weights = the mu of the wrapped one)
+    net = M.MeanFieldVI(copy.deepcopy(plain), prior={'mu': 0.0, 'sigma': 0.05}, device=device, reparam='', seed=3, n_samples=2)
+    net.set_sampling(False)                                              # w = mu: comparable with the plain net
+    convs_p = [m for m in plain.modules() if isinstance(m, torch.nn.Conv2d)]
+    convs_w = [m for m in net.modules() if hasattr(m, "W_mu")]
+    with torch.no_grad():
+        for a, b in zip(convs_p, convs_w):
+            a.weight.copy_(b.W_mu); a.bias.copy_(b.bias_mu)
+    x = torch.rand(1, 8, 32, 32, device=device)
+    for _ in range(3):
+        out = net(x)                                                     # 2 forwards per call
+        for _ in range(2):
+            ref = plain(x)
+    assert float((out[0] - ref[0]).abs().max()) < 1e-4 * float(ref.abs().max())
+    bn_p = [m for m in plain.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    bn_w = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for a, b in zip(bn_p, bn_w):
+        assert int(b.num_batches_tracked) == 6 == int(a.num_batches_tracked)
+        assert float((a.running_mean - b.running_mean).abs().max()) < 1e-5 * max(1.0, float(a.running_mean.abs().max()))
+        assert float((a.running_var - b.running_var).abs().max()) < 1e-4 * float(a.running_var.abs().max())
+    sd = net.state_dict()
+    assert all(k in sd for k in ("net.1.0.1.1.running_mean",)) or any(k.endswith("running_var") for k in sd)
+    plain.eval(); net.eval()
+    with torch.no_grad():
+        o_eval = net(x); r_eval = plain(x)
+    assert float((o_eval[0] - r_eval[0]).abs().max()) < 1e-4 * float(r_eval.abs().max())
+    assert int(bn_w[0].num_batches_tracked) == 6                         # eval forwards leave the statistics alone
+    with pytest.raises(Exception, match="eval mode"):
+        net(x).sum().backward()
+    net.train()
+    assert net(x).shape == (2, 2, 32, 32)
 
 
 @pytest.mark.parametrize("method", ["dip", "mcd", "sgld"])

@@ -187,3 +187,40 @@ def test_runner_config_devices_and_jobs(tmp_path):
     assert devices == ["cuda:0", "cuda:1"] and "devices" not in rp and "bo_results_path" not in rp
     assert cands == [dict(temp=1e-6, sigma=1e-5), dict(temp=2e-6, sigma=1e-5)]
     assert runner.load_config(str(p), "mfvi") == (cands, rp)
+
+
+@pytest.mark.parametrize("task,method", [("den", "mfvi"), ("sr", "mcd"), ("ct", "mfvi"), ("inp", "sgld"), ("den", "dip")])
+def test_artifacts_open_in_the_reference_notebooks(tmp_path, task, method):
+    """save.npz as the runner writes it (mfvi_dip_mia_amd.artifacts, pure host code) replayed through the reads of
+    eval_denoising.ipynb:79-82,339-342,363-364 / eval_sr.ipynb / eval_ct.ipynb / eval_inp.ipynb: np.load(allow_pickle=True), the
+    `.flat[0][method]` dicts, the image keys of the task and the shape arithmetic of the error / uncertainty cells; plus the PNG set
+    of plot=True (bayesian_optimization.py:201-258, :1418-1422)."""
+    from mfvi_dip_mia_amd import artifacts as A
+    rng = np.random.default_rng(0)
+    H, W, n_it, show = 32, 48, 301, 10
+    n_snap = n_it // show + 1
+    C = 3 if task == "inp" else 1
+    head = {"den": (rng.random((1, H, W)), rng.random((1, H, W))), "sr": (rng.random((1, H, W)), rng.random((H // 4, W // 4))),
+            "ct": (rng.random((1, 1, H, W)), rng.random((1, 1, 45, W))), "inp": (rng.random((3, H, W)), (rng.random((1, H, W)) > 0.2).astype(np.float32))}[task]
+    mse_c, mse_g = rng.random(n_it) * 0.02, rng.random(n_it) * 0.01
+    psnrs, ssims = 20 + rng.random((n_it, 3)), rng.random((n_it, 3))
+    recons, unc, ale = rng.random((n_snap, C, H, W)), rng.random((n_snap, C, H, W)) * 1e-3, rng.random((n_snap, 1, H, W)) * 1e-2
+    run_dir = str(tmp_path)
+    A.write_locals(run_dir, task=task, method=method, num_iter=n_it - 1)
+    A.save_npz(run_dir, task, method, head, mse_c, mse_g, recons, unc, ale, psnrs, ssims)
+    z = np.load(os.path.join(run_dir, "save.npz"), allow_pickle=True)
+    assert set(z.files) == set(A.HEAD_KEYS[task]) | {A.MSE_KEY[task], "mse_gt", "recons", "uncerts", "uncerts_ale", "psnrs", "ssims"}
+    r = A.read_like_notebooks(os.path.join(run_dir, "save.npz"), task, method)
+    assert r["psnr_curve"].shape == (4, 3) and r["final_recon"].shape == (H, W)
+    if method != "dip":
+        assert r["errvar"].shape[-2:] == (H, W) and r["uncerts"].shape[-2:] == (H, W)
+    with open(os.path.join(run_dir, "locals.txt"), "a") as f:
+        A.plot_results({method: mse_c}, {method: mse_g}, {method: psnrs}, {method: ssims}, run_dir, f)
+    A.snapshot_pngs(run_dir, method, 200, mse_c, mse_g, psnrs, recons[-1], None if method == "dip" else unc[-1], None if method == "dip" else ale[-1])
+    if task == "sr":
+        A.sr_input_png(run_dir, head[0], head[1], 4)
+    want = {"mse_noisy.png", "mse_gt.png", "psnrs.png", "ssims.png", "out_avg.png", "loss_%s.png" % method} | (set() if method == "dip" else {"out_var.png", "out_ale.png"})
+    want |= {"input.png"} if task == "sr" else set()
+    assert want <= set(os.listdir(run_dir))
+    txt = open(os.path.join(run_dir, "locals.txt")).read()
+    assert "%s PSNR_max" % method in txt and "%s SSIM_max" % method in txt and "num_iter = 300" in txt
