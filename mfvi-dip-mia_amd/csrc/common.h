@@ -199,7 +199,8 @@ __device__ __forceinline__ ChanFwd chan_fwd(const TView& v, int k, int c)
 __device__ __forceinline__ float apply_fwd(const ChanFwd& c, float y, int act, float slope)
 {
     float v = __builtin_fmaf(y - c.mean, c.scale, c.beta);
-    if (act & 1) v = v > 0.f ? v : v * slope;
+    const float se = (act & 1) ? slope : 1.f;      // uniform: LeakyReLU(slope), or the identity written as slope 1
+    v = v > 0.f ? v : v * se;
     if (act & MFVI_ACT_SQUARE) v = v * v;
     return v;
 }
