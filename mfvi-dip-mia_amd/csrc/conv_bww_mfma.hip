@@ -361,8 +361,8 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
     const bool forced = cfg != 0;
     if (!cfg) {
         // heuristic: stage dy once for up to 48 input channels when the layer has them; 8 waves when the tile is big
-        const int nb = g.Cin > 32 ? 3 : (g.Cin > 16 ? 2 : 1);
-        cfg = nb | ((nb >= 2 ? 9 : 4) << 8) | ((nb >= 2 ? 1 : 6) << 16);
+        const int nb = g.ks == 5 ? 1 : (g.Cin > 32 ? 3 : (g.Cin > 16 ? 2 : 1));
+        cfg = nb | ((nb >= 2 || g.ks == 5 ? 9 : 4) << 8) | ((nb >= 2 ? 1 : 6) << 16);
     }
     // aligned float4 staging of the specialised variant: image rows, sample strides and base pointers multiples of 4 floats
     const bool vec_ok = !(g.W & 3) && g.W >= 4 && !(g.Wo & 3) && !(in.sstride & 3) && !((uintptr_t)in.data & 15) && !(gy.gstride & 3) &&
@@ -408,6 +408,13 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
     if (g.ks == 3 && g.stride == 1) LAUNCH_NB(3, 1)
     if (g.ks == 3 && g.stride == 2) LAUNCH_NB(3, 2)
     if (g.ks == 1 && g.stride == 1) LAUNCH_NB(1, 1)
+    // 5x5 layers (inpainting nets): 25 accumulator fragments per 16-channel input tile, so one input tile per block
+    if (g.ks == 5 && nb == 1) {
+        if (g.stride == 1) { if (nt == 256) LAUNCH(5, 1, 1, 256, false) if (nt == 512 && !spec) LAUNCH(5, 1, 1, 512, false) if (nt == 512 && spec) LAUNCH(5, 1, 1, 512, true) }
+        if (g.stride == 2) { if (nt == 256) LAUNCH(5, 2, 1, 256, false) if (nt == 512 && !spec) LAUNCH(5, 2, 1, 512, false) if (nt == 512 && spec) LAUNCH(5, 2, 1, 512, true) }
+        return -3;
+    }
+    if (g.ks == 5) return -3;
 #undef LAUNCH_NB
 #undef LAUNCH
     return -2;

@@ -57,7 +57,8 @@ struct MCfg {
 #ifndef MFVI_CC0
 #define MFVI_CC0 4
 #endif
-    static constexpr int CC = !BIGC ? ((KS == 3 && STRIDE == 1) ? MFVI_CC0 : 8) : (KS == 1 ? (TH >= 16 ? MFVI_CC1 / 2 : MFVI_CC1) : 32);
+    // (5x5 layers of the inpainting nets: 4 channels too — their windows carry a 4-row / 4-column halo, 25 taps per channel step)
+    static constexpr int CC = !BIGC ? (((KS == 3 && STRIDE == 1) || KS == 5) ? MFVI_CC0 : 8) : (KS == 1 ? (TH >= 16 ? MFVI_CC1 / 2 : MFVI_CC1) : 32);
     static constexpr int NF = TH / 2;                              // pixel fragments per wave (TH/4 rows x 2 halves)
     static constexpr int KK = KS * KS;
     static constexpr int IN_TH = (TH - 1) * STRIDE + KS;
@@ -66,7 +67,7 @@ struct MCfg {
     // halo (the tile starts at a multiple of 32 columns, images are a multiple of 4 wide), so a row is WV floats and the first
     // column a tap needs sits at XOFF (+1 less for backward-data, whose halo is KS-1 instead of KS/2).
     static constexpr int HALO4 = KS > 1 ? 4 : 0;
-    static constexpr int WV = ((HALO4 ? 3 : 0) + IN_TW + 3) / 4 * 4;   // 40 (3x3), 68 (3x3 stride 2), 32 (1x1)
+    static constexpr int WV = ((HALO4 ? HALO4 - KS / 2 : 0) + IN_TW + 3) / 4 * 4;   // 40 (3x3, 5x5), 68 (3x3 stride 2), 72 (5x5 stride 2), 32 (1x1)
     static constexpr int PITCH = WV;
     static constexpr int PLANE = pitch16(IN_TH * PITCH);           // == 16 (mod 32)
     static constexpr int CTP = pitch16(CT);                        // == 16 (mod 32)
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             } else {
                 const int row = wv * (TH / 4) + (f >> 1), col = (f & 1) * 16 + l15;
                 if constexpr (PH) boff[f] = l4 * PLANE + (wv * (TH / 8)) * 24 + l15 + 3;      // window row (R + r + ky)/2, R = wv*TH/4 even; column l15 + (parity + kx)/2 + 3
-                else boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? ((MODE == 0 || FF) ? 3 : 2) : 0);
+                else boff[f] = l4 * PLANE + row * STRIDE * PITCH + col * STRIDE + (Cfg::HALO4 ? Cfg::HALO4 - ((MODE == 0 || FF) ? P : KS - 1) : 0);
             }
         }
         const int aoff = l4 * CTP + l15;
@@ -887,32 +888,37 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         const int mf = forced & 255, th = (forced >> 8) & 255;
         forced_T = (forced >> 16) & 255;
         if (th & 128) {        // FLAT tiles: 3x3 stride-1 kernels on domains up to 130 wide
-            if constexpr (KS == 3 && STRIDE == 2) {      // stride-2 forward on small outputs (MODE 1 always runs the stride-1 kernel)
+            if constexpr (KS >= 3 && STRIDE == 2) {      // stride-2 forward on small outputs (MODE 1 always runs the stride-1 kernel)
                 if (OW > 32) return -3;
                 if ((th & 127) == 8) { if (mf == 1) GO_(1, 8, true) if (mf == 2) GO_(2, 8, true) if (mf == 4) GO_(4, 8, true) }
                 if ((th & 127) == 4) { if (mf == 1) GO_(1, 4, true) if (mf == 2) GO_(2, 4, true) if (mf == 4) GO_(4, 4, true) }
                 if ((th & 127) == 2) { if (mf == 1) GO_(1, 2, true) if (mf == 2) GO_(2, 2, true) if (mf == 4) GO_(4, 2, true) }
             }
-            if constexpr (KS == 3 && STRIDE == 1) {
-                if (OW > 130) return -3;
-                if ((th & 127) == 16) { if (OH * OW >= 256) GO_MF_FLAT(mf, 16) return -3; }
-                if ((th & 127) == 8) { GO_MF_FLAT(mf, 8) if (mf == 4) GO_(4, 8, true) }
+            if constexpr (KS >= 3 && STRIDE == 1) {
+                if (OW > 132) return -3;
+                if constexpr (KS == 3) { if ((th & 127) == 16) { if (OH * OW >= 256) GO_MF_FLAT(mf, 16) return -3; } }
+                if ((th & 127) == 8) { if constexpr (KS == 3) GO_MF_FLAT(mf, 8) else { if (mf == 1) GO_(1, 8, true) if (mf == 2) GO_(2, 8, true) } if (mf == 4) GO_(4, 8, true) }
                 // 128- and 64-pixel tiles for the 8x8 / 10x10 maps at the bottom of the hour-glass (a 256-pixel tile is 25-39% full there)
                 if ((th & 127) == 4) { if (mf == 1) GO_(1, 4, true) if (mf == 2) GO_(2, 4, true) if (mf == 4) GO_(4, 4, true) }
                 if ((th & 127) == 2) { if (mf == 1) GO_(1, 2, true) if (mf == 2) GO_(2, 2, true) if (mf == 4) GO_(4, 2, true) }
             }
             return -3;
         }
-        if (th == 16) { if constexpr (STRIDE == 1) { if (OH >= 16) GO_MF(mf, 16) } return -3; }
-        if (th == 8) { GO_MF(mf, 8) if (mf == 4) GO(4, 8) }
+        if (th == 16) { if constexpr (STRIDE == 1 && KS != 5) { if (OH >= 16) GO_MF(mf, 16) } return -3; }
+        if (th == 8) { if constexpr (KS == 5) { if (mf == 1) GO(1, 8) if (mf == 2) GO(2, 8) } else GO_MF(mf, 8) if (mf == 4) GO(4, 8) }
         return -3;
     }
-    if constexpr (STRIDE == 1) {
-        if (OH >= 16)
-            for (int i = 0; i < 4; ++i) if (order[i] <= 3 && !(MODE == 0 && order[i] == 3) && blocks(order[i], 16) >= want) GO_MF(order[i], 16)
+    if constexpr (KS == 5) {       // 25 taps per channel step: the variants are kept to 8-row tiles with 1, 2 or 4 output fragments
+        for (int mf : {4, 2}) if (blocks(mf, 8) >= want && MOUT >= 16 * mf) { if (mf == 4) GO(4, 8) GO(2, 8) }
+        GO(1, 8)
+    } else {
+        if constexpr (STRIDE == 1) {
+            if (OH >= 16)
+                for (int i = 0; i < 4; ++i) if (order[i] <= 3 && !(MODE == 0 && order[i] == 3) && blocks(order[i], 16) >= want) GO_MF(order[i], 16)
+        }
+        for (int i = 0; i < 4; ++i) if (blocks(order[i], 8) >= want) { GO_MF(order[i], 8) if (order[i] == 4) GO(4, 8) }
+        GO(1, 8)
     }
-    for (int i = 0; i < 4; ++i) if (blocks(order[i], 8) >= want) { GO_MF(order[i], 8) if (order[i] == 4) GO(4, 8) }
-    GO(1, 8)
 #undef GO_MF_FLAT
 #undef GO_MF
 #undef GO
@@ -932,14 +938,16 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
     if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
     if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
     if (g.ks == 1 && g.stride == 1) return launch_variant<1, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
+    if (g.ks == 5 && g.stride == 1) return launch_variant<5, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
+    if (g.ks == 5 && g.stride == 2) return launch_variant<5, 2, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
     return -2;
 }
 
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w, long long wstride, float* dxp, long long dxp_sstride,
                               int n_samples, hipStream_t st, const FoldFuse* fuse)
 {
-    if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks == 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
-    if ((long long)g.Cin * (g.H + 2) * (g.W + 2) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
+    if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks >= 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
+    if ((long long)g.Cin * (g.H + 4) * (g.W + 4) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
     // aligned float4 (stride 2: float2) staging of the gradient and of the conv output it is normalised with
     const int wa = g.stride == 2 ? 1 : 3;
     if ((g.Wo & wa) || g.Wo < (wa + 1) || (gy.gstride & wa) || ((uintptr_t)gy.ga & 15) || (gy.y && ((gy.ystride & wa) || ((uintptr_t)gy.y & 15)))) return -2;
@@ -953,5 +961,6 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
     }
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     if (g.ks == 1) return launch_variant<1, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
+    if (g.ks == 5) return launch_variant<5, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     return -2;
 }
