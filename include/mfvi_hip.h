@@ -8,7 +8,9 @@
  *
  * Conventions
  *  - plain C: opaque handles, raw DEVICE pointers, sizes, a hipStream_t passed as void*.
- *  - every call is asynchronous on `stream` and allocates nothing; the caller owns all buffers.
+ *  - every call is asynchronous on `stream` and allocates nothing; the caller owns all buffers.  One exception: mfvi_plan_create
+ *    hipMallocs the plan's small device tables (BatchNorm, weight-sampling, gradient-reduction, Dropout2d entries; a few KB) and the
+ *    plan lazily creates one low-priority side stream with its events; mfvi_plan_destroy releases them.
  *  - return value: 0 = ok, <0 = argument/shape error, >0 = hipError_t.  mfvi_last_error() returns a
  *    thread-local message for the last non-zero return.  Nothing throws across the boundary.
  *  - tensors are fp32, NCHW with N = MC sample index; parameters live in three flat fp32 blocks
