@@ -79,8 +79,9 @@ class _KLFunction(torch.autograd.Function):
 
 class MeanFieldVI(nn.Module):
     def __init__(self, net, prior=None, posteriors=None, kl_type='reverse', reparam='local', replace_layers='all',
-                 device=torch.device('cpu'), seed=None, n_samples=1):
+                 device=torch.device('cpu'), seed=None, n_samples=1, autotune=True):
         super().__init__()
+        self._autotune = bool(autotune)      # False: keep the built-in tiling heuristics (no ~1 s search on the first forward of a shape)
         # reparam == 'local' (the reference's default): every conv becomes a Conv2dLRT (sampling in activation space); anything else
         # (the runners pass ''): Conv2dRT (sampling in weight space) — freq_to_bayes.py:22-29
         self._lrt = reparam == 'local'
@@ -363,7 +364,7 @@ class MeanFieldVI(nn.Module):
         cin, H, W = x3.shape
         plan = self._plan_for(cin, H, W, self.n_samples)
         mu, rho, bn = self._blocks()
-        if not getattr(plan, "tuned", False):      # first use of this plan: pick the fastest tiling per layer (one-time)
+        if self._autotune and not getattr(plan, "tuned", False):      # first use of this plan: pick the fastest tiling per layer (one-time)
             plan.autotune(mu, rho, bn, x3, self.n_samples)
         sample = bool(self.training and self._sampling)
         step = self._step
@@ -451,8 +452,9 @@ class FusedNet(MeanFieldVI):
     The reference runs these nets as ordinary torch modules, so this wrapper is the one extra line a caller adds; parameters keep
     the reference's names below the `net.` prefix (net.<path>.weight / .bias and the BatchNorm keys) and are views of one flat buffer."""
 
-    def __init__(self, net, device=torch.device('cuda'), seed=None, n_samples=1):
+    def __init__(self, net, device=torch.device('cuda'), seed=None, n_samples=1, autotune=True):
         nn.Module.__init__(self)
+        self._autotune = bool(autotune)
         device = torch.device(device)
         if device.type != 'cuda':
             raise NotImplementedError("this implementation runs on the GPU only (device=%s); there is no CPU path" % device)
