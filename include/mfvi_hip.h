@@ -110,7 +110,10 @@ int mfvi_forward(mfvi_plan* plan, const void* mu, const void* rho, const float* 
                  uint64_t seed, uint32_t step, uint32_t k0, int n_samples, int sample_weights,
                  void* workspace, float* out, void* stream);
 /* Backward of the same call (workspace must still hold its activations).  dout: [n_samples][Cout][H][W].
- * dmu/drho/dbn are ACCUMULATED into (+=).  dz (optional): [n_samples][Cin][H][W]. */
+ * dmu/drho/dbn are ACCUMULATED into (+=).  dz (optional): [n_samples][Cin][H][W].
+ * mu / rho / bn must still hold the values the forward saw: the first backward after a forward with the same (pointers, seed, step,
+ * k0, n_samples) re-uses the weights that forward drew (they are in the workspace) instead of drawing them again; any further
+ * backward of the same forward draws them afresh from mu / rho. */
 int mfvi_backward(mfvi_plan* plan, const void* mu, const void* rho, const float* bn, const float* z,
                   uint64_t seed, uint32_t step, uint32_t k0, int n_samples, int sample_weights,
                   void* workspace, const float* dout, float* dmu, float* drho, float* dbn, float* dz, void* stream);

@@ -10,7 +10,7 @@ def rep(a, b, n=1):
     assert a in s, a[:60]
     s = s.replace(a, b, n)
 rep("    int nx, ny, nz;", "    int nx, ny, nz; long long* prof;")
-rep("    using Cfg = MCfg<KS, STRIDE, MF, TH>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,", "    long long T[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64();\n#define TICK(i) { const long long n_ = clock64(); T[i] += n_ - tc; tc = n_; }\n    using Cfg = MCfg<KS, STRIDE, MF, TH>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,")
+rep("    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,", "    long long T[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64();\n#define TICK(i) { const long long n_ = clock64(); T[i] += n_ - tc; tc = n_; }\n    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,")
 rep("    const int H = g.H, W = g.W;\n    const int SH = MODE == 0 ? H : g.Ho", "    TICK(0)\n    const int H = g.H, W = g.W;\n    const int SH = MODE == 0 ? H : g.Ho")
 rep('''        set_tile(ptile); prefetch(pc0);
         __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
@@ -55,7 +55,7 @@ rep('''        __syncthreads();                                  // (S0)
         TICK(2)
         for (int it = 0; it < n_iters; ++it) {
             const int tile = tile_begin + it / n_chunks''')
-rep("            if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});\n", "            if (cc4 == 8) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});\n            TICK(5)\n")
+rep("            if (ci == n_chunks - 1) {\n                // ---- epilogue ----", "            TICK(5)\n            if (ci == n_chunks - 1) {\n                // ---- epilogue ----")
 rep('''            lds_barrier();
         }
         if (do_stats) {''', '''            TICK(6)
@@ -74,9 +74,9 @@ rep('''                              s_red[0][q][which] + s_red[1][q][which] + s
     TICK(7)
     if (A.prof && bx == 1 && by == 0 && k == 3 && (threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) A.prof[(threadIdx.x >> 6) * 8 + i] = T[i];
 }''')
-rep("    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1};",
-    "    static long long* prof = [] { long long* p = nullptr; if (getenv(\"MFVI_PROF\")) { (void)hipMalloc((void**)&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();\n    MfmaArgs A{xin, gin, g, w, wstride, out, dxp, dxp_sstride, 0, 0, 1, 0, 0, 0, prof};")
+rep("    A.vec_out = MODE == 0 &&",
+    "    static long long* prof = [] { long long* p = nullptr; if (getenv(\"MFVI_PROF\")) { (void)hipMalloc((void**)&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();\n    A.prof = prof;\n    A.vec_out = MODE == 0 &&")
 rep("        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO(MF_, TH_)",
-    "        if (prof) { long long h[64]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost); fprintf(stderr, \"MODE %d KS %d mf %d th %d T %d tiles %d my %d chunks/tile %d\\n\", MODE, KS, MF_, TH_, A.tiles_per_block, A.n_tiles, my, (RED + 7) / 8); for (int w = 0; w < 8; ++w) { fprintf(stderr, \"wave %d:\", w); for (int i = 0; i < 8; ++i) fprintf(stderr, \" %lld\", h[w * 8 + i]); fprintf(stderr, \"\\n\"); } } \\\n        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO(MF_, TH_)")
+    "        if (prof) { long long h[64]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost); fprintf(stderr, \"MODE %d KS %d mf %d th %d flat %d ff %d T %d tiles %d my %d chunks/tile %d\\n\", MODE, KS, MF_, TH_, (int)(FL_), (int)ff, A.tiles_per_block, A.n_tiles, my, (RED + Cfg::CC - 1) / Cfg::CC); for (int w = 0; w < 8; ++w) { fprintf(stderr, \"wave %d:\", w); for (int i = 0; i < 8; ++i) fprintf(stderr, \" %lld\", h[w * 8 + i]); fprintf(stderr, \"\\n\"); } } \\\n        return (int)hipGetLastError();                                                                                     \\\n    }\n#define GO(MF_, TH_)")
 rep("#include <cstdlib>", "#include <cstdlib>\n#include <cstdio>")
 open(p, 'w').write(s)
