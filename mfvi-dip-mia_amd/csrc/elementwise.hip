@@ -256,8 +256,11 @@ __global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has
             }
         }
         *reinterpret_cast<float4*>(o + (long long)gi * 4) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sum += (double)v[j]; sq += (double)v[j] * (double)v[j]; }
+        // BN statistics: float partials over the 4 pixels of the group, folded into the thread's fp64 sums (the per-element fp64 converts /
+        // adds ran at half rate and made this kernel VALU-bound)
+        { const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+          const float q4 = __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
+          sum += (double)s4; sq += (double)q4; }
     }
     if (out.stats != nullptr) {
         const double sa = block_sum_d(sum, s_red);
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has
 constexpr int CB_TH = 16, CB_TW = 64;
 constexpr int CB_ROWS = 2 * CB_TH + 2, CB_PITCH = CB_TW + 1;      // staged rows; entries per even / odd plane row
 
-__global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, int has_a, float* __restrict__ ga_a,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void concat_up_bwd_kernel(GView gc, TView a, int has_a, float* __restrict__ ga_a,
                                                             long long ga_a_sstride, double* __restrict__ bsums_a,
                                                             TView b, float* __restrict__ ga_b, long long ga_b_sstride,
                                                             double* __restrict__ bsums_b, int tiles_x, int nearest)
@@ -305,64 +308,85 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
     float* __restrict__ go = (from_a ? ga_a + (long long)k * ga_a_sstride : ga_b + (long long)k * ga_b_sstride) + (long long)cd * HWd;
     const bool dst_bn = dst.stats != nullptr;
 
+    // All global loads of a phase are issued before anything depends on them (address math first, then the batch): with one
+    // dependent load per loop trip a block paid one memory latency per trip (9 trips of staging + 4 of output) and the kernel ran at
+    // latency x trips instead of bandwidth.
     if (from_a) {
         // hi-res tile rows 2*m0 .. 2*m0+2*CB_TH-1, cols 2*n0 .. 2*n0+2*CB_TW-1, as float2 (W is even)
         const int r0 = 2 * m0, q0 = 2 * n0;
-        for (int i = t; i < 2 * CB_TH * CB_TW; i += 256) {
-            const int r = r0 + i / CB_TW, q = q0 + (i % CB_TW) * 2;
-            if (r >= H || q >= W) continue;
-            const long long pix = (long long)r * W + q;
-            const f2a g2 = *reinterpret_cast<const f2a*>(gap + pix);
-            float d[2] = {g2.x, g2.y};
-            if (cat_bn) { const f2a y2 = *reinterpret_cast<const f2a*>(ycp + pix); d[0] = apply_bwd(cg, g2.x, y2.x); d[1] = apply_bwd(cg, g2.y, y2.y); }
-            if (dst_bn) {
-                const f2a yv2 = *reinterpret_cast<const f2a*>(yd + pix);
-                const float yy[2] = {yv2.x, yv2.y};
+        constexpr int NA = 2 * CB_TH * CB_TW / 256;
+        f2a g2[NA], y2[NA], yv2[NA]; int pixs[NA];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float v = __builtin_fmaf(yy[j] - ch.mean, ch.scale, ch.beta);
-                    if (dst.act && !(v > 0.f)) d[j] *= dst.slope;
-                    sg += (double)d[j]; sgx += (double)d[j] * (double)((yy[j] - ch.mean) * ch.rstd);
+        for (int j = 0; j < NA; ++j) {
+            const int i = t + 256 * j, r = r0 + i / CB_TW, q = q0 + (i % CB_TW) * 2;
+            const bool ok = r < H && q < W;
+            pixs[j] = ok ? r * W + q : -1;
+            const int pix = ok ? pixs[j] : 0;
+            g2[j] = *reinterpret_cast<const f2a*>(gap + pix);
+            if (cat_bn) y2[j] = *reinterpret_cast<const f2a*>(ycp + pix);
+            if (dst_bn) yv2[j] = *reinterpret_cast<const f2a*>(yd + pix);
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            if (pixs[j] < 0) continue;
+            float d[2] = {g2[j].x, g2[j].y};
+            if (cat_bn) { d[0] = apply_bwd(cg, g2[j].x, y2[j].x); d[1] = apply_bwd(cg, g2[j].y, y2[j].y); }
+            if (dst_bn) {
+                const float yy[2] = {yv2[j].x, yv2[j].y};
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const float v = __builtin_fmaf(yy[l] - ch.mean, ch.scale, ch.beta);
+                    if (dst.act && !(v > 0.f)) d[l] *= dst.slope;
                 }
+                // float partials over the pair, folded into the thread's fp64 sums
+                sg += (double)(d[0] + d[1]);
+                sgx += (double)__builtin_fmaf(d[0], (yy[0] - ch.mean) * ch.rstd, d[1] * ((yy[1] - ch.mean) * ch.rstd));
             }
             f2a o2; o2.x = d[0]; o2.y = d[1];
-            *reinterpret_cast<f2a*>(go + pix) = o2;
+            *reinterpret_cast<f2a*>(go + pixs[j]) = o2;
         }
     } else {
         // ---- stage dy of the hi-res window: local row lr <-> hi-res row 2*m0-1+lr, local col lc <-> hi-res col 2*n0-1+lc;
         //      even lc -> s_e[lr][lc/2], odd lc -> s_o[lr][lc/2].  Slot 0: lc 0; slots 1..CB_TW: lc (2s-1, 2s); slot CB_TW+1: lc 2*CB_TW+1.
         const int gr0 = 2 * m0 - 1, gc0 = 2 * n0 - 1;
-        constexpr int SLOTS = CB_TW + 2;
-        for (int i = t; i < CB_ROWS * SLOTS; i += 256) {
-            const int lr = i / SLOTS, sl = i - lr * SLOTS;
-            const int gr = gr0 + lr;
-            const bool rok = gr >= 0 && gr < H;
-            if (sl == 0 || sl == SLOTS - 1) {
-                const int lc = sl == 0 ? 0 : 2 * CB_TW + 1, gq = gc0 + lc;
-                float d = 0.f;
-                if (rok && gq >= 0 && gq < W) {
-                    const long long pix = (long long)gr * W + gq;
-                    d = cat_bn ? apply_bwd(cg, gap[pix], ycp[pix]) : gap[pix];
-                }
-                if (sl == 0) s_e[lr][0] = d; else s_o[lr][CB_TW] = d;
-            } else {
-                const int gq = gc0 + 2 * sl - 1;                   // even hi-res column: float2-aligned
-                float d0 = 0.f, d1 = 0.f;
-                if (rok && gq < W) {
-                    const long long pix = (long long)gr * W + gq;
-                    const f2a g2 = *reinterpret_cast<const f2a*>(gap + pix);
-                    d0 = g2.x; d1 = g2.y;
-                    if (cat_bn) { const f2a y2 = *reinterpret_cast<const f2a*>(ycp + pix); d0 = apply_bwd(cg, g2.x, y2.x); d1 = apply_bwd(cg, g2.y, y2.y); }
-                }
-                s_o[lr][sl - 1] = d0; s_e[lr][sl] = d1;
-            }
+        constexpr int SLOTS = CB_TW + 2, NS = (CB_ROWS * SLOTS + 255) / 256;
+        // slot sl of a window row = the aligned pair at hi-res columns (2*n0 - 2 + 2*sl, +1): .x -> s_o[lr][sl-1], .y -> s_e[lr][sl]
+        // (slot 0 only contributes its .y, the last slot only its .x); branch-free: clamped address, zeroed when outside the image
+        f2a g2[NS], y2[NS]; int ok[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int i = min(t + 256 * j, CB_ROWS * SLOTS - 1), lr = i / SLOTS, sl = i - lr * SLOTS;
+            const int gr = gr0 + lr, gq = 2 * n0 - 2 + 2 * sl;
+            ok[j] = gr >= 0 && gr < H && gq >= 0 && gq < W;
+            const int pix = ok[j] ? gr * W + gq : 0;
+            g2[j] = *reinterpret_cast<const f2a*>(gap + pix);
+            if (cat_bn) y2[j] = *reinterpret_cast<const f2a*>(ycp + pix);
+        }
+        // raw destination values of this thread's outputs (LeakyReLU' and x-hat of the BN-backward sums), requested with the batch above
+        const int nl = t & 63, n = n0 + nl;
+        float ydv[CB_TH / 4];
+#pragma unroll
+        for (int q = 0; q < CB_TH / 4; ++q) {
+            const int m = m0 + (t >> 6) + 4 * q;
+            ydv[q] = (dst_bn && m < dst.H && n < dst.W) ? yd[m * dst.W + n] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int i = t + 256 * j, lr = i / SLOTS, sl = i - lr * SLOTS;
+            if (i >= CB_ROWS * SLOTS) continue;
+            float d0 = g2[j].x, d1 = g2[j].y;
+            if (cat_bn) { d0 = apply_bwd(cg, g2[j].x, y2[j].x); d1 = apply_bwd(cg, g2[j].y, y2[j].y); }
+            if (!ok[j]) { d0 = 0.f; d1 = 0.f; }
+            if (sl >= 1) s_o[lr][sl - 1] = d0;
+            if (sl <= CB_TW) s_e[lr][sl] = d1;
         }
         __syncthreads();
         // ---- adjoint of the bilinear x2 gather (align_corners=False).  Low-res row m feeds hi-res rows 2m-1..2m+2 with weights
         //      .25 .75 .75 .25; at the borders the clamped taps collapse: row 0 gets 1.0 from hi-res row 0 and the last row 1.0
         //      from the last hi-res row (columns alike).
-        const int nl = t & 63, n = n0 + nl;
-        for (int ml = t >> 6; ml < CB_TH; ml += 4) {
+#pragma unroll
+        for (int qq = 0; qq < CB_TH / 4; ++qq) {
+            const int ml = (t >> 6) + 4 * qq;
             const int m = m0 + ml;
             if (m >= dst.H || n >= dst.W) continue;
             float wy[4], wx[4];
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(256) void concat_up_bwd_kernel(GView gc, TView a, i
             }
             const long long pix = (long long)m * dst.W + n;
             if (dst_bn) {
-                const float yv = yd[pix];
+                const float yv = ydv[qq];
                 const float v = __builtin_fmaf(yv - ch.mean, ch.scale, ch.beta);
                 if (dst.act && !(v > 0.f)) d *= dst.slope;
                 sg += (double)d; sgx += (double)d * (double)((yv - ch.mean) * ch.rstd);
