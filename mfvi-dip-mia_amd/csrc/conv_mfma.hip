@@ -109,7 +109,7 @@ template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool
 __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
 {
     static_assert(!PH || (MODE == 1 && KS == 3 && !FLAT && !BIGC), "phase decomposition: 3x3 backward-data on rectangular tiles");
-    static_assert(!FF || (MODE == 1 && KS == 3 && STRIDE == 1 && !PH && !BIGC), "fused fold: 3x3 stride-1 backward-data");
+    static_assert(!FF || (MODE == 1 && KS == 3 && STRIDE == 1 && !PH), "fused fold: 3x3 stride-1 backward-data");
     using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;
     constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
@@ -165,19 +165,35 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     //   MODE 0: rows = output channel m, global range ((m0+m)*Cin + c0)*KK + [0, cc*KK),   element -> (kk, tap)
     //   MODE 1: rows = reduction channel kk, range ((c0+kk)*Cin + m0)*KK + [0, mt*KK),     element -> (m, flipped tap)
     // The launcher guarantees Cin % 4 == 0 and w_off % 4 == 0, so every row range is a whole number of aligned float4.
-    auto load_slab = [&](int c0, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
+    // Two halves: slab_fetch requests up to NR float4 per thread (items th + j*nthr, j0 <= j < j0 + NR) into registers — all loads of a
+    // batch are in flight together — and slab_commit scatters them into LDS.  (One dependent load per loop trip cost a block one memory
+    // latency per trip: 9 trips for the weight-stationary slab of the 36->16 layer, and one EXPOSED latency per reduction stage in the
+    // chunked mode, which is what the 8x8 / 16x16 layers at the bottom of the hour-glass spent their time on.)
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wk + g.w_off);
+    auto slab_fetch = [&](auto nr_c, int c0, int cc, int cc4, int th, int nthr, int j0, float4* __restrict__ r) {
+        constexpr int NR = decltype(nr_c)::value;
         const int rows = MODE == 0 ? CT : cc4;
         const int valid_rows = MODE == 0 ? mt : cc;
         const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
-        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wk + g.w_off);
-        for (int idx = th; idx < rows * G; idx += nthr) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int idx = th + (j0 + j) * nthr;
             const int row = idx / G, gi = idx - row * G;
-            float w[4] = {0.f, 0.f, 0.f, 0.f};
-            if (row < valid_rows) {
-                const int blk = (MODE == 0 ? (((m0 + row) * g.Cin + c0) * KK) : (((c0 + row) * g.Cin + m0) * KK)) / 4 + gi;
-                const float4 a = w4[blk];
-                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-            }
+            r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < rows * G && row < valid_rows)
+                r[j] = w4[(MODE == 0 ? (((m0 + row) * g.Cin + c0) * KK) : (((c0 + row) * g.Cin + m0) * KK)) / 4 + gi];
+        }
+    };
+    auto slab_commit = [&](auto nr_c, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr, int j0, const float4* __restrict__ r) {
+        constexpr int NR = decltype(nr_c)::value;
+        const int rows = MODE == 0 ? CT : cc4;
+        const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int idx = th + (j0 + j) * nthr;
+            if (idx >= rows * G) continue;
+            const int row = idx / G, gi = idx - row * G;
+            const float w[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
                 const int rel = gi * 4 + l, q = rel / KK, tap = rel - q * KK;
@@ -185,6 +201,8 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                 else wdst[((KK - 1 - tap) * REDP + kbase + row) * CTP + q] = w[l];
             }
         }
+    };
+    auto slab_pad = [&](int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
         if (MODE == 0 && cc4 > cc)       // pad the last 4-channel step with zero weights
             for (int idx = th; idx < (cc4 - cc) * KK * CT; idx += nthr) {
                 const int m = idx % CT, r = idx / CT, kk = cc + r % (cc4 - cc), tap = r / (cc4 - cc);
@@ -196,13 +214,26 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                 wdst[(tap * REDP + kbase + kk) * CTP + m] = 0.f;
             }
     };
+    // whole range in batches of 8 float4 per thread (weight-stationary slab; chunks too big for the register pipeline)
+    auto load_slab = [&](int c0, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
+        const int rows = MODE == 0 ? CT : cc4;
+        const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
+        const int trips = (rows * G + nthr - 1) / nthr;
+        constexpr std::integral_constant<int, 8> eight{};
+        for (int j0 = 0; j0 < trips; j0 += 8) {
+            float4 r[8];
+            slab_fetch(eight, c0, cc, cc4, th, nthr, j0, r);
+            slab_commit(eight, cc, cc4, kbase, wdst, th, nthr, j0, r);
+        }
+        slab_pad(cc, cc4, kbase, wdst, th, nthr);
+    };
 
     const int tile_begin = bx * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
     if (tile_begin >= tile_end) return;
     const int n_iters = (tile_end - tile_begin) * n_chunks;
 
     if (WS)       // the whole slab, once, by all 8 waves
-        for (int c0 = 0; c0 < RED; c0 += CC) { const int cc = min(CC, RED - c0); load_slab(c0, cc, (cc + 3) & ~3, c0, s_w, tid, 512); }
+        load_slab(0, RED, (RED + 3) & ~3, 0, s_w, tid, 512);
 
     const int H = g.H, W = g.W;
     const int SH = MODE == 0 ? H : g.Ho, SW = MODE == 0 ? W : g.Wo;
@@ -371,20 +402,35 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         auto store = [&](int c0, float* __restrict__ dst) { if constexpr (FLAT) store_s(c0, dst); else store_v(c0, dst); };
         auto chunk_of = [&](int it, int& tile, int& c0) { tile = tile_begin + it / n_chunks; c0 = (it % n_chunks) * CC; };
 
+        // chunked weights (!WS): the slab of a stage travels global -> registers -> LDS one stage ahead like the activations when it is
+        // at most SLAB_NR float4 per producer thread; bigger chunks (many output fragments x 32-channel stages) load in place, batched
+        constexpr int SLAB_ITEMS = 4 * MF * CC * KK;                         // float4 of one full chunk
+        constexpr int SLAB_NR = (SLAB_ITEMS + 255) / 256;
+        constexpr bool SLAB_PIPE = !WS && SLAB_NR <= 12;
+        constexpr std::integral_constant<int, SLAB_PIPE ? SLAB_NR : 1> snr{};
+        float4 wreg[SLAB_PIPE ? SLAB_NR : 1];
+        auto wfetch = [&](int c0) { if constexpr (SLAB_PIPE) { const int cc = min(CC, RED - c0); slab_fetch(snr, c0, cc, (cc + 3) & ~3, t, 256, 0, wreg); } };
+        auto wstore = [&](int c0, float* __restrict__ wdst) {
+            if constexpr (!WS) {
+                const int cc = min(CC, RED - c0), cc4 = (cc + 3) & ~3;
+                if constexpr (SLAB_PIPE) { slab_commit(snr, cc, cc4, 0, wdst, t, 256, 0, wreg); slab_pad(cc, cc4, 0, wdst, t, 256); }
+                else load_slab(c0, cc, cc4, 0, wdst, t, 256);
+            }
+        };
         int ptile, pc0;
         chunk_of(0, ptile, pc0);
-        set_tile(ptile); prefetch(pc0);
+        set_tile(ptile); prefetch(pc0); wfetch(pc0);
         __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
         store(pc0, s_x[0]);
-        if (!WS) { const int cc = min(CC, RED - pc0); load_slab(pc0, cc, (cc + 3) & ~3, 0, s_w, t, 256); }
-        if (n_iters > 1) { int nt, nc; chunk_of(1, nt, nc); if (nt != ptile) { set_tile(nt); ptile = nt; } prefetch(nc); }
+        wstore(pc0, s_w);
+        if (n_iters > 1) { int nt, nc; chunk_of(1, nt, nc); if (nt != ptile) { set_tile(nt); ptile = nt; } prefetch(nc); wfetch(nc); }
         lds_barrier();                                    // (A) chunk 0 published
         for (int it = 0; it < n_iters; ++it) {
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 store(nc, s_x[(it + 1) & 1]);
-                if (!WS) { const int cc = min(CC, RED - nc); load_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
-                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
+                wstore(nc, s_w + ((it + 1) & 1) * WCHUNK);
+                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); wfetch(c2); }
             }
             lds_barrier();
         }
@@ -835,7 +881,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
         using Cfg = MCfg<KS, STRIDE, MF_, TH_>;                                                                            \
         A.tiles_x = (OW + 31) / 32;                                                                                        \
         A.n_tiles = A.tiles_x * ((OH + TH_ - 1) / TH_);                                                                    \
-        if ((FL_) && ff && (OW & 15)) return -3;      /* fused fold on FLAT tiles: a 16-pixel fragment must not straddle two rows */ \
+        if ((FL_) && ff && (OW & 7)) return -3;       /* fused fold on FLAT tiles: rows are whole half-fragments (8x8 maps: two rows per fragment) */ \
         if (FL_) {                                                                                                         \
             A.ow = OW; A.wpitch = (OW - 1) * STRIDE + KS;                                                                  \
             int rt = (TH_ * 32) / OW;                                                                                      \
@@ -847,7 +893,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             A.n_tiles = (OH + rt - 1) / rt;                                                                                \
         }                                                                                                                  \
         const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
-        constexpr bool CAN_BIG = (KS == 1 && !(FL_)) || (KS == 3 && STRIDE == 1 && MODE == 0 && (FL_) && TH_ <= 4);   /* backward-data stages two tensors: measured slower with big stages */ \
+        constexpr bool CAN_BIG = (KS == 1 && !(FL_)) || (KS == 3 && STRIDE == 1 && (FL_) && TH_ <= 4);   /* 3x3: the small maps at the bottom of the hour-glass, both passes */ \
         constexpr bool CAN_PH = MODE == 1 && KS == 3 && !(FL_);                                                           \
         const bool ph = CAN_PH && g.stride == 2 && phase_on() && (g.Wo & 3) == 0 && (gin.gstride & 3) == 0 && (!gin.y || (gin.ystride & 3) == 0); \
         using BigCfg = MCfg<KS, STRIDE, MF_, TH_, CAN_BIG>;                                                                \
@@ -863,7 +909,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (lds_big + ws_bytes > 150 * 1024) big = false;                                                              \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
@@ -873,7 +920,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (big) ck_bytes = ck_big;                                                                                    \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
-            if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \

@@ -1,6 +1,6 @@
 """Developer aid: patch csrc/conv_mfma.hip IN PLACE with per-phase cycle counters (clock64 around prefetch / store / weight
 sampling / barrier waits / MFMA / epilogue of one block) printed by the launcher when MFVI_PROF is set.  Columns per wave:
-T0 prologue+slab, T1 prefetch, T2 barrier waits, T3 store, T4 chunk weight sampling, T5 MFMA, T6 epilogue (consumer) /
+T0 prologue+slab, T1 prefetch, T2 barrier waits, T3 store, T4 weight chunk regs -> LDS, T5 MFMA, T6 epilogue (consumer) /
 vmcnt wait (producer), T7 tail.  Restore the file with `git checkout` afterwards; never commit the patched kernel."""
 import sys
 p = sys.argv[1] if len(sys.argv) > 1 else 'mfvi-dip-mia_amd/csrc/conv_mfma.hip'
@@ -12,21 +12,24 @@ def rep(a, b, n=1):
 rep("    int nx, ny, nz;", "    int nx, ny, nz; long long* prof;")
 rep("    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,", "    long long T[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64();\n#define TICK(i) { const long long n_ = clock64(); T[i] += n_ - tc; tc = n_; }\n    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,")
 rep("    const int H = g.H, W = g.W;\n    const int SH = MODE == 0 ? H : g.Ho", "    TICK(0)\n    const int H = g.H, W = g.W;\n    const int SH = MODE == 0 ? H : g.Ho")
-rep('''        set_tile(ptile); prefetch(pc0);
+rep('''        set_tile(ptile); prefetch(pc0); wfetch(pc0);
         __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
-        store(pc0, s_x[0]);''', '''        set_tile(ptile); prefetch(pc0);
+        store(pc0, s_x[0]);
+        wstore(pc0, s_w);''', '''        set_tile(ptile); prefetch(pc0); wfetch(pc0);
         TICK(1)
         __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
         TICK(2)
         store(pc0, s_x[0]);
-        TICK(3)''')
+        TICK(3)
+        wstore(pc0, s_w);
+        TICK(4)''')
 rep('''        lds_barrier();                                    // (A) chunk 0 published
         for (int it = 0; it < n_iters; ++it) {
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 store(nc, s_x[(it + 1) & 1]);
-                if (!WS) { const int cc = min(CC, RED - nc); load_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
-                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
+                wstore(nc, s_w + ((it + 1) & 1) * WCHUNK);
+                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); wfetch(c2); }
             }
             lds_barrier();
         }''', '''        TICK(1)
@@ -39,9 +42,9 @@ rep('''        lds_barrier();                                    // (A) chunk 0 
                 TICK(6)
                 store(nc, s_x[(it + 1) & 1]);
                 TICK(3)
-                if (!WS) { const int cc = min(CC, RED - nc); load_slab(nc, cc, (cc + 3) & ~3, 0, s_w + ((it + 1) & 1) * WCHUNK, t, 256); }
+                wstore(nc, s_w + ((it + 1) & 1) * WCHUNK);
                 TICK(4)
-                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); }
+                if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); wfetch(c2); }
                 TICK(1)
             }
             lds_barrier();

@@ -387,6 +387,38 @@ def test_tilings_do_not_change_results(M, shape):
                 assert relerr(a, b) < 2e-5, (name, which, cand)
 
 
+@pytest.mark.parametrize("shape", [(132, 128, 8, 8), (128, 128, 16, 16), (68, 64, 8, 16)])
+def test_small_map_tilings_do_not_change_results(M, shape):
+    """The 8x8 / 16x16 maps at the bottom of the hour-glass: FLAT tiles of 2 / 4 / 8 rows-worth of pixels with 32-channel stages in both
+    passes (backward-data with the fold in its epilogue included, two map rows per 16-pixel fragment at width 8), against the
+    rectangular 8-row tiling."""
+    cin, cout, H, W = shape
+    n, seed = 3, 79
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    enc = lambda a, b, c: a | b << 8 | c << 16
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, enc(1, 8, 1))); M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    tried = 0
+    cands = [(mf, th | 128, 1) for th in (2, 4, 8) for mf in (1, 2, 4)] + [(2, 8, 1)]
+    for which in (0, 1):
+        for cand in cands:
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc(*cand)))
+            try:
+                got = _run_plan(plan, P, seed, n, z, dout)
+            except M._lib.MfviError:          # a tiling this shape does not admit (-3)
+                continue
+            finally:
+                M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc(1, 8, 1)))
+            tried += 1
+            assert relerr(got[0], ref[0]) < 1e-6, ("out", which, cand)
+            for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+                assert relerr(a, b) < 2e-5, (name, which, cand)
+    assert tried >= 12
+
+
 @pytest.mark.parametrize("shape", [(16, 32, 64, 64), (64, 128, 32, 32)])
 def test_stride2_tilings_do_not_change_results(M, shape):
     """Stride-2 layers: the phase-decomposed backward-data on rectangular tiles (every fragment count / tile height / tiles per block),
