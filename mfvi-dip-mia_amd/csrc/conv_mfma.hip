@@ -38,10 +38,11 @@ constexpr int EPP = 36;                 // row pitch of the per-wave output tran
 
 constexpr int pitch16(int n) { return ((n + 15) / 32) * 32 + 16; }      // smallest p >= n with p % 32 == 16
 
-template <int KS, int STRIDE, int MF, int TH, bool BIGC = false>
+template <int KS, int STRIDE, int MF, int TH, bool BIGC = false, bool REM = false>
 struct MCfg {
     static constexpr int TW = 32;
     static constexpr int CT = 16 * MF;
+    static constexpr int CTX = CT + (REM ? 4 : 0);                // REM: the block that holds the layer's last 4 output channels carries them too
     // Reduction channels per activation stage.  A stage costs one barrier and (with the one-stage register prefetch) about one
     // global-load latency; a 1x1 convolution has so little matrix work per 8 channels (2 k-steps) that its loop ran at
     // latency x Cin/8 (26 us for 128 -> 4 channels on a 16x16 map).  Its windows are small (no halo), so with BIGC it stages 32
@@ -70,7 +71,7 @@ struct MCfg {
     static constexpr int WV = ((HALO4 ? HALO4 - KS / 2 : 0) + IN_TW + 3) / 4 * 4;   // 40 (3x3, 5x5), 68 (3x3 stride 2), 72 (5x5 stride 2), 32 (1x1)
     static constexpr int PITCH = WV;
     static constexpr int PLANE = pitch16(IN_TH * PITCH);           // == 16 (mod 32)
-    static constexpr int CTP = pitch16(CT);                        // == 16 (mod 32)
+    static constexpr int CTP = pitch16(CTX);                       // == 16 (mod 32)
     static constexpr int X_FLOATS = CC * PLANE;
 };
 
@@ -105,15 +106,29 @@ struct MfmaArgs {
 //     col j == 1:    B(ky, kx=2) += B(ky, kx=0)         col j == W-2:  B(ky, kx=0) += B(ky, kx=2)       (corners: both, 4 terms)
 // on the pixel operand B of the lanes concerned — a few extra LDS reads in the border tiles, no extra MFMA, and neither the (H+2)x(W+2)
 // padded-gradient scratch (written and re-read: 2 x 100 MB per pass of up_9) nor the finalize_dx launch exist any more.
-template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false, bool PH = false, bool FF = false>
-__global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
+// REM (with FF, rectangular 8-row tiles): the skip() concats have 4 + 32/64/128 channels, so backward-data's output channels come as
+// 36 / 68 / 132 = whole 16-channel fragments + 4.  Instead of padding the 4 to a fifth / ninth ... fragment (33 / 18 / 9 % of the MFMAs of
+// those layers), the block that owns the last fragments also carries the 4 extra channels on v_mfma_f32_4x4x1_16B_f32: 16 independent
+// 4x4 outer products per instruction — block b = lane >> 2 takes the B operand's (k = b >> 2, pixels 4*(b & 3)..+3), i.e. exactly the
+// lanes of the 16x16x4 pixel fragment already in registers, against A = w[extra channel lane & 3][k = lane >> 4] — 8 cycles instead of
+// a 32-cycle fragment.  Each lane accumulates its own k-slice; the four slices are added across lanes (l15 + 16*l4) in the epilogue.
+template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false, bool PH = false, bool FF = false, bool REM = false>
+__global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= (REM ? 8 : 16) ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
 {
     static_assert(!PH || (MODE == 1 && KS == 3 && !FLAT && !BIGC), "phase decomposition: 3x3 backward-data on rectangular tiles");
     static_assert(!FF || (MODE == 1 && KS == 3 && STRIDE == 1 && !PH), "fused fold: 3x3 stride-1 backward-data");
-    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;
-    constexpr int TW = Cfg::TW, CT = Cfg::CT, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
+    static_assert(!REM || (FF && !FLAT && !BIGC && TH == 8), "remainder channels: fused-fold backward-data on rectangular 8-row tiles");
+    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC, REM>;
+    constexpr int TW = Cfg::TW, CT = Cfg::CT, CTX = Cfg::CTX, CC = Cfg::CC, NF = Cfg::NF, KK = Cfg::KK, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, CTP = Cfg::CTP;
     constexpr int WCHUNK = KK * CC * CTP;               // floats of one weight chunk (non-WS double buffer)
+    // PEPI (fused fold on rectangular tiles): the PRODUCER waves run the fold.  The consumers only dump a finished tile's accumulators into
+    // s_out and go on with the next tile's MFMAs; the producers — idle for ~40 % of a tile otherwise — read it back row-wise during the next
+    // tile's stages (raw x from global, LeakyReLU', BN-backward sums, coalesced float4 stores of ga).  The hand-over rides on the stage
+    // barriers that exist anyway: the dump precedes the barrier that ends the tile's last stage, the three parts of the fold run in
+    // the next tile's stages 0 .. 2, i.e. before the barrier that precedes the next dump (n_chunks >= 4: launcher).
+    constexpr bool PEPI = FF && !FLAT;
+    constexpr int OP = TH * 32 + 4;                      // channel pitch of s_out: 4 * OP == 16 (mod 32), the four 4-channel row groups of a dump land in distinct banks
     static_assert(MODE == 0 || STRIDE == 1, "backward-data always stages a stride-1 window");
     // MODE 1 of a stride-2 layer (g.stride == 2): the transposed convolution is the same full correlation over the ZERO-STUFFED
     // gradient G[r][c] = dy[r/2][c/2] (r, c even), formed on the fly; 3/4 of the MACs multiply zeros, but on the matrix cores.
@@ -126,8 +141,9 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     __shared__ ChanFwd s_ch[(MODE == 0 || KS == 1 || FF) ? MFVI_MAX_C : 1];
     __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
-    __shared__ double s_red[4][CT][2];
-    __shared__ __align__(16) float s_ep[FLAT ? 1 : 4][FLAT ? 1 : 16][FLAT ? 4 : EPP];    // rectangular tiles: epilogue transpose, one slab per consumer wave
+    __shared__ double s_red[4][CTX][2];
+    __shared__ __align__(16) float s_ep[(FLAT || PEPI) ? 1 : 4][(FLAT || PEPI) ? 1 : 16][(FLAT || PEPI) ? 4 : EPP];    // rectangular tiles: epilogue transpose, one slab per consumer wave
+    __shared__ __align__(16) float s_out[PEPI ? CTX * OP : 4];
 
     const ConvGeom& g = A.g;
     const int tid = threadIdx.x;
@@ -142,6 +158,8 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     const int RED = MODE == 0 ? g.Cin : g.Cout;
     const int MOUT = MODE == 0 ? g.Cout : g.Cin;
     const int mt = min(CT, MOUT - m0);
+    const bool rem_blk = REM && by == A.ny - 1;                      // this block also owns the layer's last 4 output channels (m0 + CT ..)
+    const int mtx = mt + (rem_blk ? 4 : 0);
     const int REDP = WS ? ((RED + 3) & ~3) : CC;                     // reduction-channel pitch of s_w
     const int n_chunks = (RED + CC - 1) / CC;
 
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         constexpr int NR = decltype(nr_c)::value;
         const int rows = MODE == 0 ? CT : cc4;
         const int valid_rows = MODE == 0 ? mt : cc;
-        const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
+        const int G = ((MODE == 0 ? cc : mtx) * KK) >> 2;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int idx = th + (j0 + j) * nthr;
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     auto slab_commit = [&](auto nr_c, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr, int j0, const float4* __restrict__ r) {
         constexpr int NR = decltype(nr_c)::value;
         const int rows = MODE == 0 ? CT : cc4;
-        const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
+        const int G = ((MODE == 0 ? cc : mtx) * KK) >> 2;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int idx = th + (j0 + j) * nthr;
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     // whole range in batches of 8 float4 per thread (weight-stationary slab; chunks too big for the register pipeline)
     auto load_slab = [&](int c0, int cc, int cc4, int kbase, float* __restrict__ wdst, int th, int nthr) {
         const int rows = MODE == 0 ? CT : cc4;
-        const int G = ((MODE == 0 ? cc : mt) * KK) >> 2;
+        const int G = ((MODE == 0 ? cc : mtx) * KK) >> 2;
         const int trips = (rows * G + nthr - 1) / nthr;
         constexpr std::integral_constant<int, 8> eight{};
         for (int j0 = 0; j0 < trips; j0 += 8) {
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 
         // chunked weights (!WS): the slab of a stage travels global -> registers -> LDS one stage ahead like the activations when it is
         // at most SLAB_NR float4 per producer thread; bigger chunks (many output fragments x 32-channel stages) load in place, batched
-        constexpr int SLAB_ITEMS = 4 * MF * CC * KK;                         // float4 of one full chunk
+        constexpr int SLAB_ITEMS = (CTX / 4) * CC * KK;                      // float4 of one full chunk
         constexpr int SLAB_NR = (SLAB_ITEMS + 255) / 256;
         constexpr bool SLAB_PIPE = !WS && SLAB_NR <= 12;
         constexpr std::integral_constant<int, SLAB_PIPE ? SLAB_NR : 1> snr{};
@@ -417,6 +435,53 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                 else load_slab(c0, cc, cc4, 0, wdst, t, 256);
             }
         };
+        // ---- PEPI: the fold of a dumped tile, item idx = t + 256*j of [channel][row][float4 column]; the channel of (wave, j) is wave-uniform.
+        //      Three parts (items j == part mod 3), one per stage 0..2 of the next tile (n_chunks >= 4: launcher), so a part's raw-x loads
+        //      are few registers and fly while the stage is staged.
+        constexpr int NIT = PEPI ? (CTX * TH * 8 + 255) / 256 : 1, NIT3 = (NIT + 2) / 3;
+        float fsum[NIT], fxs[NIT]; float4 fxr[NIT3];
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) { fsum[j] = 0.f; fxs[j] = 0.f; }
+        auto fold_fetch = [&](int tile, auto part_c) {       // request the raw x of the part's items
+            constexpr int PART = decltype(part_c)::value;
+            if constexpr (PEPI) {
+                if (!fuse_sums) return;
+                const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+                const float* __restrict__ xq = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * H * W;
+#pragma unroll
+                for (int j = PART; j < NIT; j += 3) {
+                    const int idx = t + 256 * j, ch = idx / (TH * 8), pr = py0 + ((idx >> 3) % TH), pc = px0 + 4 * (idx & 7);
+                    fxr[j / 3] = (ch < mtx && pr < H && pc < W) ? *reinterpret_cast<const float4*>(xq + ch * H * W + pr * W + pc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto fold_do = [&](int tile, auto part_c) {
+            constexpr int PART = decltype(part_c)::value;
+            if constexpr (PEPI) {
+                const int px0 = (tile % A.tiles_x) * TW, py0 = (tile / A.tiles_x) * TH;
+                float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * H * W;
+#pragma unroll
+                for (int j = PART; j < NIT; j += 3) {
+                    const int idx = t + 256 * j, ch = idx / (TH * 8), row = (idx >> 3) % TH, pr = py0 + row, pc = px0 + 4 * (idx & 7);
+                    if (ch < mtx && pr < H && pc < W) {
+                        const float4 v = *reinterpret_cast<const float4*>(&s_out[ch * OP + row * 32 + 4 * (idx & 7)]);
+                        float dd[4] = {v.x, v.y, v.z, v.w};
+                        if (fuse_sums) {
+                            const float yy[4] = {fxr[j / 3].x, fxr[j / 3].y, fxr[j / 3].z, fxr[j / 3].w};
+                            const ChanFwd cf = s_ch[m0 + ch];
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) {
+                                const float vv = __builtin_fmaf(yy[l] - cf.mean, cf.scale, cf.beta);
+                                if (A.xin.act && !(vv > 0.f)) dd[l] *= A.xin.slope;
+                                fsum[j] += dd[l]; fxs[j] = __builtin_fmaf(dd[l], (yy[l] - cf.mean) * cf.rstd, fxs[j]);
+                            }
+                        }
+                        *reinterpret_cast<float4*>(o + ch * H * W + pr * W + pc) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                    }
+                }
+            }
+        };
+        constexpr std::integral_constant<int, 0> p0{}; constexpr std::integral_constant<int, 1> p1{}; constexpr std::integral_constant<int, 2> p2{};
         int ptile, pc0;
         chunk_of(0, ptile, pc0);
         set_tile(ptile); prefetch(pc0); wfetch(pc0);
@@ -426,15 +491,36 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         if (n_iters > 1) { int nt, nc; chunk_of(1, nt, nc); if (nt != ptile) { set_tile(nt); ptile = nt; } prefetch(nc); wfetch(nc); }
         lds_barrier();                                    // (A) chunk 0 published
         for (int it = 0; it < n_iters; ++it) {
+            // PEPI: stage ci of a tile carries part ci of the PREVIOUS tile's fold (parts 0 .. n_chunks - 2)
+            const int fci = it % n_chunks, ftile = tile_begin + it / n_chunks - 1;
+            const bool fold_now = PEPI && it >= n_chunks && fci < 3;
+            if (fold_now) { if (fci == 0) fold_fetch(ftile, p0); else if (fci == 1) fold_fetch(ftile, p1); else fold_fetch(ftile, p2); }
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 store(nc, s_x[(it + 1) & 1]);
                 wstore(nc, s_w + ((it + 1) & 1) * WCHUNK);
                 if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); wfetch(c2); }
             }
+            if (fold_now) { if (fci == 0) fold_do(ftile, p0); else if (fci == 1) fold_do(ftile, p1); else fold_do(ftile, p2); }
             lds_barrier();
         }
-        if ((MODE == 0 && A.out.stats != nullptr) || fuse_sums) __syncthreads();        // (Z) consumers publish their BN partial sums
+        if constexpr (PEPI) {       // the block's last tile, then this thread's BN-backward partials: the channel of (wave, j) is wave-uniform
+            fold_fetch(tile_end - 1, p0); fold_do(tile_end - 1, p0); fold_fetch(tile_end - 1, p1); fold_do(tile_end - 1, p1); fold_fetch(tile_end - 1, p2); fold_do(tile_end - 1, p2);
+            if (fuse_sums) {
+#pragma unroll
+                for (int j = 0; j < NIT; ++j) {
+                    float a = fsum[j], b = fxs[j];
+#pragma unroll
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) { a += __shfl_xor(a, o2, 64); b += __shfl_xor(b, o2, 64); }
+                    const int ch = (t + 256 * j) / (TH * 8);          // same for all lanes of the wave (64 | TH * 8)
+                    if (lane == 0 && ch < mtx) {
+                        double* dst = A.fbsums + ((long long)k * g.Cin + m0 + ch) * 2;
+                        atomicAdd(dst, (double)a); atomicAdd(dst + 1, (double)b);
+                    }
+                }
+            }
+        }
+        if ((MODE == 0 && A.out.stats != nullptr) || (fuse_sums && !PEPI)) __syncthreads();        // (Z) consumers publish their BN partial sums
     } else {
         // ======================= consumer waves =======================
         int boff[FLAT ? 1 : NF], boffk[FLAT ? NF : 1][FLAT ? KS : 1], frc[FLAT ? NF : 1];
@@ -456,9 +542,11 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
         const int aoff = l4 * CTP + l15;
         const int wtap = REDP * CTP;
         f32x4 acc[MF][NF];
-        const bool do_stats = (MODE == 0 && A.out.stats != nullptr) || fuse_sums;
+        f32x4 accx[REM ? NF : 1];                          // REM: the 4 extra channels, this lane's k-slice
+        const int xoff = CT + (l15 & 3) - l15;             // from aoff to the extra channels' weights of reduction channel l4
+        const bool do_stats = (MODE == 0 && A.out.stats != nullptr) || (fuse_sums && !PEPI);
         // BN statistics of this wave's outputs: float partial sums per tile, folded into the wave's fp64 slots in LDS
-        if (do_stats && lane < CT) { s_red[wv][lane][0] = 0.0; s_red[wv][lane][1] = 0.0; }
+        if (do_stats) for (int q = lane; q < CTX; q += 64) { s_red[wv][q][0] = 0.0; s_red[wv][q][1] = 0.0; }
         __syncthreads();                                  // (S0)
         lds_barrier();                                    // (A)
         for (int it = 0; it < n_iters; ++it) {
@@ -474,6 +562,10 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                 for (int a = 0; a < MF; ++a)
 #pragma unroll
                     for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (REM) {
+#pragma unroll
+                    for (int b = 0; b < NF; ++b) accx[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
             // Fused fold on rectangular tiles: the epilogue needs the raw input tensor x (LeakyReLU' and the x-hat of the BN-backward sums)
             // at the tile's output pixels.  All its float4 are requested together — before the MFMAs of the tile's last chunk when the
@@ -482,7 +574,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #ifndef MFVI_YPRE_EARLY_MAX
 #define MFVI_YPRE_EARLY_MAX 12
 #endif
-            constexpr bool YPRE = MODE == 1 && !FLAT && (KS == 1 || FF);
+            constexpr bool YPRE = MODE == 1 && !FLAT && !PEPI && (KS == 1 || FF);
             constexpr bool YPRE_EARLY = YPRE && MF * NF <= MFVI_YPRE_EARLY_MAX;
             float4 ypre[YPRE ? MF : 1][YPRE ? NF / 2 : 1][2];
             auto load_ypre = [&]() {
@@ -514,11 +606,26 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #define MFMA_STAGES 2
 #endif
                 constexpr int SG = MFMA_STAGES;
-                float a[SG][MF], b[SG][NF];
-                auto load = [&](int q, float (&aa)[MF], float (&bb)[NF]) {
+                // Rectangular tiles: a fragment is 16 pixels of ONE row, so the row part of the reflection adjoint moves to the weight operand:
+                //   row 1:   A'(ky=0) = A(ky=0) + A(ky=2)      row H-2:   A'(ky=2) = A(ky=2) + A(ky=0)
+                // (the same products, summed on the A side; the corner term comes out of A' x B').  One extra A read per border-row k-step
+                // instead of up to two extra B reads per fragment; the column part stays on B.
+                constexpr bool AROW = FF && SPR && !FLAT;
+                float a[SG][MF], b[SG][NF], ax[SG], ao[SG][AROW ? MF : 1], axo[SG];
+                auto load = [&](int q, float (&aa)[MF], float (&bb)[NF], float& axx, float (&aoo)[AROW ? MF : 1], float& axoo) {
                     const int tap = q / STEPS, st_ = q % STEPS, ky = tap / KS, kx = tap % KS;
 #pragma unroll
                     for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + (sbase + st_) * 4 * CTP + i * 16];
+                    if constexpr (REM) axx = wq[tap * wtap + (sbase + st_) * 4 * CTP + xoff]; else axx = 0.f;
+                    axoo = 0.f;
+                    if constexpr (AROW) {
+                        if (ky != 1) {
+                            const int tapo = (2 - ky) * KS + kx;
+#pragma unroll
+                            for (int i = 0; i < MF; ++i) aoo[i] = wq[tapo * wtap + (sbase + st_) * 4 * CTP + i * 16];
+                            if constexpr (REM) axoo = wq[tapo * wtap + (sbase + st_) * 4 * CTP + xoff];
+                        }
+                    }
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
                         if constexpr (PH) {        // fragment f: row parity (f >> 1) & 1, column parity f & 1
@@ -535,12 +642,12 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                             int rowf, colf;
                             if constexpr (FLAT) { rowf = tpy0 + (frc[f] >> 16); colf = frc[f] & 0xffff; }
                             else { rowf = tpy0 + wv * (TH / 4) + (f >> 1); colf = tpx0 + (f & 1) * 16 + l15; }
-                            const float fr = (SPR && ky != 1 && rowf == (ky == 2 ? 1 : g.H - 2)) ? 1.f : 0.f;
+                            const float fr = (SPR && FLAT && ky != 1 && rowf == (ky == 2 ? 1 : g.H - 2)) ? 1.f : 0.f;
                             const float fc = (SPC && kx != 1 && colf == (kx == 2 ? 1 : g.W - 2)) ? 1.f : 0.f;
                             float e = 0.f;
-                            if constexpr (SPR) { if (ky != 1) e = __builtin_fmaf(fr, rd(2 - ky, kx), e); }
+                            if constexpr (SPR && FLAT) { if (ky != 1) e = __builtin_fmaf(fr, rd(2 - ky, kx), e); }
                             if constexpr (SPC) { if (kx != 1) e = __builtin_fmaf(fc, rd(ky, 2 - kx), e); }
-                            if constexpr (SPR && SPC) { if (ky != 1 && kx != 1) e = __builtin_fmaf(fr * fc, rd(2 - ky, 2 - kx), e); }
+                            if constexpr (SPR && SPC && FLAT) { if (ky != 1 && kx != 1) e = __builtin_fmaf(fr * fc, rd(2 - ky, 2 - kx), e); }
                             bb[f] += e;
                         }
                     }
@@ -553,18 +660,32 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                 // sits in `s_waitcnt lgkmcnt(0)` a dozen times per stage.  Measured on MI355X (profiles/r02_fence_ab.txt): no difference, the
                 // other two consumer waves of the SIMD fill those gaps — kept as an A/B switch.
 #pragma unroll
-                for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG]);
+                for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG], ax[q % SG], ao[q % SG], axo[q % SG]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    if (q + SG - 1 < NQ) load(q + SG - 1, a[(q + SG - 1) % SG], b[(q + SG - 1) % SG]);
+                    if (q + SG - 1 < NQ) load(q + SG - 1, a[(q + SG - 1) % SG], b[(q + SG - 1) % SG], ax[(q + SG - 1) % SG], ao[(q + SG - 1) % SG], axo[(q + SG - 1) % SG]);
                     if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
                     const int tapq = q / STEPS, kyq = tapq / KS, kxq = tapq % KS;
 #pragma unroll
-                    for (int i = 0; i < MF; ++i)
+                    for (int f = 0; f < NF; ++f) {
+                        // fragment f's row takes the other border tap's weights too (wave-uniform flag)
+                        float frw = 0.f;
+                        if constexpr (AROW) { if (kyq != 1) frw = (tpy0 + wv * (TH / 4) + (f >> 1) == (kyq == 0 ? 1 : g.H - 2)) ? 1.f : 0.f; }
 #pragma unroll
-                        for (int f = 0; f < NF; ++f)
-                            if (!PH || ((((f >> 1) + kyq) & 1) == 0 && (((f & 1) + kxq) & 1) == 0))
-                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q % SG][i], b[q % SG][f], acc[i][f], 0, 0, 0);
+                        for (int i = 0; i < MF; ++i)
+                            if (!PH || ((((f >> 1) + kyq) & 1) == 0 && (((f & 1) + kxq) & 1) == 0)) {
+                                float av = a[q % SG][i];
+                                if constexpr (AROW) { if (kyq != 1) av = __builtin_fmaf(frw, ao[q % SG][i], av); }
+                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q % SG][f], acc[i][f], 0, 0, 0);
+                            }
+                        if constexpr (REM) {
+                            if (rem_blk) {
+                                float av = ax[q % SG];
+                                if constexpr (AROW) { if (kyq != 1) av = __builtin_fmaf(frw, axo[q % SG], av); }
+                                accx[f] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, b[q % SG][f], accx[f], 0, 0, 0);
+                            }
+                        }
+                    }
                     if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -591,6 +712,28 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             }
 
             if (ci == n_chunks - 1) {
+              if constexpr (PEPI) {
+                // ---- hand the tile to the producers: accumulators -> s_out[channel][row][col] (D layout: column (pixel) = lane & 15,
+                //      row (channel) = (lane >> 4) * 4 + reg); they fold and store it while this wave runs the next tile ----
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            s_out[(i * 16 + l4 * 4 + r) * OP + (wv * (TH / 4) + (f >> 1)) * 32 + (f & 1) * 16 + l15] = acc[i][f][r];
+                if constexpr (REM) {
+                    if (rem_blk) {      // the 4 extra channels: add the four k-slices (lanes l15 + 16 * l4) first
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float v = accx[f][r]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                                if (l4 == 0) s_out[(CT + r) * OP + (wv * (TH / 4) + (f >> 1)) * 32 + (f & 1) * 16 + l15] = v;
+                            }
+                    }
+                }
+              } else {
                 // ---- epilogue ----  D layout: column (pixel) = lane & 15, row (channel) = (lane >> 4) * 4 + reg.
                 // 32-bit element offsets from a wave-uniform base keep the address math out of the VGPR budget.
                 const int px0 = FLAT ? 0 : (tile % A.tiles_x) * TW, py0 = FLAT ? tile * A.rt : (tile / A.tiles_x) * TH;
@@ -821,6 +964,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                         }
                 }
                             }
+              }
             }
             lds_barrier();
         }
@@ -828,9 +972,9 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             // One fp64 atomic per (channel, moment) per BLOCK: same-address float atomics serialise at the memory side
             // (~0.2 us each), so per-tile or per-wave atomics would dominate the kernel.
             __syncthreads();                              // (Z)
-            if (t < CT * 2) {
+            if (t < CTX * 2) {
                 const int q = t >> 1, which = t & 1;
-                if (q < mt)
+                if (q < mtx)
                     atomicAdd((MODE == 0 ? A.out.stats + ((long long)k * g.Cout + m0 + q) * 2 : A.fbsums + ((long long)k * g.Cin + m0 + q) * 2) + which,
                               s_red[0][q][which] + s_red[1][q][which] + s_red[2][q][which] + s_red[3][q][which]);
             }
@@ -876,11 +1020,13 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && cost(order[j]) < cost(order[j - 1]); --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
     const long long want = 768;
     int forced_T = 0;
+    bool want_rem = false;      // tune bit 64 of the tile-height field: carry the layer's last 4 output channels on the 4x4x1 matrix instruction
 #define GO_(MF_, TH_, FL_)                                                                                                 \
     {                                                                                                                      \
         using Cfg = MCfg<KS, STRIDE, MF_, TH_>;                                                                            \
         A.tiles_x = (OW + 31) / 32;                                                                                        \
         A.n_tiles = A.tiles_x * ((OH + TH_ - 1) / TH_);                                                                    \
+        if (ff && !(FL_) && RED <= 3 * Cfg::CC) return -3;   /* producer-side fold: three parts in stages 0..2 of the next tile, dump at the last stage */ \
         if ((FL_) && ff && (OW & 7)) return -3;       /* fused fold on FLAT tiles: rows are whole half-fragments (8x8 maps: two rows per fragment) */ \
         if (FL_) {                                                                                                         \
             A.ow = OW; A.wpitch = (OW - 1) * STRIDE + KS;                                                                  \
@@ -892,16 +1038,20 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             A.rt = rt; A.nwin = ((rt - 1) * STRIDE + KS) * A.wpitch;                                                       \
             A.n_tiles = (OH + rt - 1) / rt;                                                                                \
         }                                                                                                                  \
-        const int my = (MOUT + 16 * MF_ - 1) / (16 * MF_);                                                                 \
+        constexpr bool CAN_REM = CAN_FF && !(FL_) && TH_ == 8;                                                            \
+        if (want_rem && !(CAN_REM && ff && (MOUT & 15) == 4 && (MOUT - 4) % (16 * MF_) == 0)) return -3;                  \
+        const bool rem = want_rem;                                                                                         \
+        const int my = rem ? (MOUT - 4) / (16 * MF_) : (MOUT + 16 * MF_ - 1) / (16 * MF_);                                 \
         constexpr bool CAN_BIG = (KS == 1 && !(FL_)) || (KS == 3 && STRIDE == 1 && (FL_) && TH_ <= 4);   /* 3x3: the small maps at the bottom of the hour-glass, both passes */ \
         constexpr bool CAN_PH = MODE == 1 && KS == 3 && !(FL_);                                                           \
         const bool ph = CAN_PH && g.stride == 2 && phase_on() && (g.Wo & 3) == 0 && (gin.gstride & 3) == 0 && (!gin.y || (gin.ystride & 3) == 0); \
         using BigCfg = MCfg<KS, STRIDE, MF_, TH_, CAN_BIG>;                                                                \
         bool big = CAN_BIG && RED >= 64;                                                                                   \
-        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * Cfg::CTP;                                              \
+        using RemCfg = MCfg<KS, STRIDE, MF_, TH_, false, CAN_REM>;                                                         \
+        const size_t ws_bytes = sizeof(float) * (size_t)KK * RED4 * (rem ? RemCfg::CTP : Cfg::CTP);                        \
         const size_t ck_big = 2 * sizeof(float) * (size_t)KK * BigCfg::CC * Cfg::CTP;                                      \
         const size_t lds_big = 2 * sizeof(float) * (size_t)BigCfg::X_FLOATS + 24 * 1024;   /* static LDS of the big-stage variant */ \
-        size_t ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * Cfg::CTP;                                             \
+        size_t ck_bytes = 2 * sizeof(float) * (size_t)KK * Cfg::CC * (rem ? RemCfg::CTP : Cfg::CTP);                       \
         const long long nb = (long long)A.n_tiles * my * n_samples;                                                        \
         int T = (int)(nb / 512); T = T < 1 ? 1 : (T > 8 ? 8 : T);                                                          \
         if (forced_T > 0) T = forced_T;                                                                                    \
@@ -909,7 +1059,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (lds_big + ws_bytes > 150 * 1024) big = false;                                                              \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
@@ -920,7 +1071,8 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (big) ck_bytes = ck_big;                                                                                    \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
-            if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
@@ -933,8 +1085,10 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
 #define GO_MF_FLAT(mf_, TH_) { if ((mf_) == 1) GO_(1, TH_, true) if ((mf_) == 2) GO_(2, TH_, true) if ((mf_) == 3) GO_(3, TH_, true) }
     const int forced = g.tune[MODE] ? g.tune[MODE] : env_tune();
     if (forced) {              // explicit tiling (mf | th << 8 | T << 16); -3 = not a valid tiling for this shape
-        const int mf = forced & 255, th = (forced >> 8) & 255;
+        const int mf = forced & 255;
+        int th = (forced >> 8) & 255;
         forced_T = (forced >> 16) & 255;
+        if (th & 64) { want_rem = true; th &= ~64; if (th != 8) return -3; }
         if (th & 128) {        // FLAT tiles: 3x3 stride-1 kernels on domains up to 130 wide
             if constexpr (KS >= 3 && STRIDE == 2) {      // stride-2 forward on small outputs (MODE 1 always runs the stride-1 kernel)
                 if (OW > 32) return -3;

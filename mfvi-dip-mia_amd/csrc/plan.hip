@@ -859,7 +859,11 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
             // candidate tilings: fwd / bwd-data (mf, th, T) = fragments x tile rows x tiles per block;
             //                    bwd-weight (nb, waves, target/256) = input tiles per block x waves x block-count target
             std::vector<int> cands;
-            if (which < 2) { for (int th : {8, 16, 8 | 128, 16 | 128, 4 | 128, 2 | 128}) for (int mf = 1; mf <= 4; ++mf) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | th << 8 | T << 16); }
+            if (which < 2) {
+                for (int th : {8, 16, 8 | 128, 16 | 128, 4 | 128, 2 | 128}) for (int mf = 1; mf <= 4; ++mf) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | th << 8 | T << 16);
+                // backward-data of the 4 + 16n-channel concat layers: the last 4 output channels on the 4x4x1 matrix instruction (th bit 64)
+                if (which == 1 && (o.g.Cin & 15) == 4) for (int mf : {1, 2, 4}) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | (8 | 64) << 8 | T << 16);
+            }
             else { for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16); }
             int best = 0; float best_ms = 1e30f;
             for (int cand : cands) {

@@ -1,7 +1,7 @@
 """Developer aid: patch csrc/conv_mfma.hip IN PLACE with per-phase cycle counters (clock64 around prefetch / store / weight
 sampling / barrier waits / MFMA / epilogue of one block) printed by the launcher when MFVI_PROF is set.  Columns per wave:
 T0 prologue+slab, T1 prefetch, T2 barrier waits, T3 store, T4 weight chunk regs -> LDS, T5 MFMA, T6 epilogue (consumer) /
-vmcnt wait (producer), T7 tail.  Restore the file with `git checkout` afterwards; never commit the patched kernel."""
+vmcnt wait (producer), T7 tail (consumer) / producer-side fold.  Restore the file with `git checkout` afterwards; never commit the patched kernel."""
 import sys
 p = sys.argv[1] if len(sys.argv) > 1 else 'mfvi-dip-mia_amd/csrc/conv_mfma.hip'
 s = open(p).read()
@@ -10,7 +10,7 @@ def rep(a, b, n=1):
     assert a in s, a[:60]
     s = s.replace(a, b, n)
 rep("    int nx, ny, nz;", "    int nx, ny, nz; long long* prof;")
-rep("    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,", "    long long T[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64();\n#define TICK(i) { const long long n_ = clock64(); T[i] += n_ - tc; tc = n_; }\n    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,")
+rep("    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC, REM>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,", "    long long T[8] = {0,0,0,0,0,0,0,0}; long long tc = clock64();\n#define TICK(i) { const long long n_ = clock64(); T[i] += n_ - tc; tc = n_; }\n    using Cfg = MCfg<KS, STRIDE, MF, TH, BIGC, REM>;\n    constexpr int TW = Cfg::TW, CT = Cfg::CT,")
 rep("    const int H = g.H, W = g.W;\n    const int SH = MODE == 0 ? H : g.Ho", "    TICK(0)\n    const int H = g.H, W = g.W;\n    const int SH = MODE == 0 ? H : g.Ho")
 rep('''        set_tile(ptile); prefetch(pc0); wfetch(pc0);
         __syncthreads();                                  // (S0) channel constants / bias / WS slab visible
@@ -24,18 +24,21 @@ rep('''        set_tile(ptile); prefetch(pc0); wfetch(pc0);
         wstore(pc0, s_w);
         TICK(4)''')
 rep('''        lds_barrier();                                    // (A) chunk 0 published
-        for (int it = 0; it < n_iters; ++it) {
+        for (int it = 0; it < n_iters; ++it) {''', '''        TICK(1)
+        lds_barrier();                                    // (A) chunk 0 published
+        TICK(2)
+        for (int it = 0; it < n_iters; ++it) {''')
+rep('''            if (fold_now) { if (fci == 0) fold_fetch(ftile, p0); else if (fci == 1) fold_fetch(ftile, p1); else fold_fetch(ftile, p2); }
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 store(nc, s_x[(it + 1) & 1]);
                 wstore(nc, s_w + ((it + 1) & 1) * WCHUNK);
                 if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); wfetch(c2); }
             }
+            if (fold_now) { if (fci == 0) fold_do(ftile, p0); else if (fci == 1) fold_do(ftile, p1); else fold_do(ftile, p2); }
             lds_barrier();
-        }''', '''        TICK(1)
-        lds_barrier();                                    // (A) chunk 0 published
-        TICK(2)
-        for (int it = 0; it < n_iters; ++it) {
+        }''', '''            if (fold_now) { if (fci == 0) fold_fetch(ftile, p0); else if (fci == 1) fold_fetch(ftile, p1); else fold_fetch(ftile, p2); }
+            TICK(7)
             if (it + 1 < n_iters) {
                 int nt, nc; chunk_of(it + 1, nt, nc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -47,6 +50,8 @@ rep('''        lds_barrier();                                    // (A) chunk 0 
                 if (it + 2 < n_iters) { int n2, c2; chunk_of(it + 2, n2, c2); if (n2 != ptile) { set_tile(n2); ptile = n2; } prefetch(c2); wfetch(c2); }
                 TICK(1)
             }
+            if (fold_now) { if (fci == 0) fold_do(ftile, p0); else if (fci == 1) fold_do(ftile, p1); else fold_do(ftile, p2); }
+            TICK(7)
             lds_barrier();
             TICK(2)
         }''')
@@ -58,7 +63,7 @@ rep('''        __syncthreads();                                  // (S0)
         TICK(2)
         for (int it = 0; it < n_iters; ++it) {
             const int tile = tile_begin + it / n_chunks''')
-rep("            if (ci == n_chunks - 1) {\n                // ---- epilogue ----", "            TICK(5)\n            if (ci == n_chunks - 1) {\n                // ---- epilogue ----")
+rep("            if (ci == n_chunks - 1) {\n              if constexpr (PEPI) {", "            TICK(5)\n            if (ci == n_chunks - 1) {\n              if constexpr (PEPI) {")
 rep('''            lds_barrier();
         }
         if (do_stats) {''', '''            TICK(6)

@@ -377,7 +377,10 @@ def test_tilings_do_not_change_results(M, shape):
     enc = lambda a, b, c: a | b << 8 | c << 16
     fwd_bwd = [(1, 8, 1), (1, 16, 1), (2, 8, 2), (3, 8, 1), (1, 8 | 128, 1), (1, 16 | 128, 1), (2, 8 | 128, 2), (1, 4 | 128, 1), (2, 2 | 128, 1), (4, 4 | 128, 1)]
     bww = [(1, 4, 1), (1, 8, 2), (2, 9, 1), (3, 9, 1), (3, 4, 2)]
-    for which, cands in ((0, fwd_bwd), (1, fwd_bwd), (2, bww)):
+    # backward-data with the layer's last 4 input channels on the 4x4x1 matrix instruction (tile-height bit 64): 36 = 2*16+4, 68 = 4*16+4 ...
+    rem = [(mf, 8 | 64, T) for mf, T in ((1, 1), (2, 2), (4, 1)) if (cin - 4) % (16 * mf) == 0]
+    assert len(rem) >= 2
+    for which, cands in ((0, fwd_bwd), (1, fwd_bwd + rem), (2, bww)):
         for cand in cands:
             M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc(*cand)))
             got = _run_plan(plan, P, seed, n, z, dout)
