@@ -12,6 +12,7 @@
 // LDS planes are pitched == 2 (mod 32) floats so the 16 channels x 2 pixels of a half-wave read hit 32 banks.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -160,44 +161,87 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         constexpr int NOP = NB * KK;
         const int vr = min(TH, Ho - (tile / tiles_x) * TH), vc4 = (min(TW, Wo - (tile % tiles_x) * TW) + 3) >> 2;
         const int NKS = vr * vc4;
-        float a[2], bq[2][NOP];
-        auto load = [&](int ks, float& aa, float (&bb)[NOP]) {
-            const int row = ks / vc4, c4 = (ks - row * vc4) * 4;
-            aa = s_g[l15 * GPLANE + row * TW + c4 + l4];
-            const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * WV + (c4 + l4) * STRIDE + XOFF;
+        // Full-width tiles with 4 MFMA waves (the hot case): wave wv owns pixel columns 4wv..4wv+3 and 4wv+16..+19 of every row, so the
+        // operands of its two k-steps per row sit at fixed offsets from two pointers that advance by one row — no address arithmetic per
+        // k-step — and the loop is software-pipelined at instruction level: LDS read q of k-step i+1, then MFMA q of k-step i, pinned in
+        // that order (every operand is requested a full k-step = 9*NB MFMAs before its use).  Written as "all reads of i+1, fence, all
+        // MFMAs of i" (the generic path below) the ~30 non-matrix instructions of a k-step issue back to back while the matrix pipe
+        // drains (in-order issue): 40 % of the pipe's rate inside the MFMA phase.
+        auto k_loop = [&](auto bias_c, auto fullw_c) {
+            constexpr bool BIAS = decltype(bias_c)::value, FULLW = decltype(fullw_c)::value;
+            float a[2], bq[2][NOP];
+            auto load = [&](int ks, float& aa, float (&bb)[NOP]) {
+                const int row = ks / vc4, c4 = (ks - row * vc4) * 4;
+                aa = s_g[l15 * GPLANE + row * TW + c4 + l4];
+                const float* xb = s_x + l15 * XPLANE + (row * STRIDE) * WV + (c4 + l4) * STRIDE + XOFF;
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int ky = 0; ky < KS; ++ky)
+                    for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) bb[b * KK + ky * KS + kx] = xb[b * 16 * XPLANE + ky * WV + kx];
-        };
-        auto fma_all = [&](float aa, const float (&bb)[NOP]) {
+                        for (int kx = 0; kx < KS; ++kx) bb[b * KK + ky * KS + kx] = xb[b * 16 * XPLANE + ky * WV + kx];
+            };
+            auto fma_all = [&](float aa, const float (&bb)[NOP]) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int q = 0; q < KK; ++q) acc[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[b * KK + q], acc[b][q], 0, 0, 0);
-            if (do_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, 1.0f, accb, 0, 0, 0);
-        };
-        int ks = wv;
-        if (ks >= NKS) return;
+                    for (int q = 0; q < KK; ++q) acc[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[b * KK + q], acc[b][q], 0, 0, 0);
+                if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, 1.0f, accb, 0, 0, 0);
+            };
+            if constexpr (FULLW && NW == 4) {
+                // MFMAs of the k-step in (aa, bb) with the reads of the k-step at (gp, xp) into (an, bn) woven in
+                auto step = [&](float aa, const float (&bb)[NOP], const float* gp, const float* xp, float& an, float (&bn)[NOP]) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < KS; ++kx) {
+                                const int q = b * KK + ky * KS + kx;
+                                bn[q] = xp[b * 16 * XPLANE + ky * WV + kx];
+                                if (q == 0) an = gp[0];
+                                acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[q], acc[b][ky * KS + kx], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, 1.0f, accb, 0, 0, 0);
+                };
+                const float* ga = s_g + l15 * GPLANE + wv * 4 + l4;
+                const float* xa = s_x + l15 * XPLANE + (wv * 4 + l4) * STRIDE + XOFF;
+                a[0] = ga[0];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < KS; ++kx) bq[0][b * KK + ky * KS + kx] = xa[b * 16 * XPLANE + ky * WV + kx];
+                for (int r = 0; r < vr; ++r) {
+                    step(a[0], bq[0], ga + 16, xa + 16 * STRIDE, a[1], bq[1]);
+                    if (r + 1 < vr) { ga += TW; xa += STRIDE * WV; }          // last row: re-read it (values unused)
+                    step(a[1], bq[1], ga, xa, a[0], bq[0]);
+                }
+                return;
+            }
+            int ks = wv;
+            if (ks >= NKS) return;
 #ifndef MFVI_FENCE
 #define MFVI_FENCE 1
 #endif
-        // scheduling fences: keep "request the next k-step's operands, then issue this k-step's MFMAs" as written (the machine scheduler
-        // otherwise sinks the ds_reads next to their uses and the wave waits on LDS with an idle matrix pipe)
-        load(ks, a[0], bq[0]);
-        for (; ks + NW < NKS; ks += 2 * NW) {
-            load(ks + NW, a[1], bq[1]);
-            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
-            fma_all(a[0], bq[0]);
-            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 * NW < NKS) load(ks + 2 * NW, a[0], bq[0]);
-            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
-            fma_all(a[1], bq[1]);
-            if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ks < NKS) fma_all(a[0], bq[0]);
+            load(ks, a[0], bq[0]);
+            for (; ks + NW < NKS; ks += 2 * NW) {
+                load(ks + NW, a[1], bq[1]);
+                if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
+                fma_all(a[0], bq[0]);
+                if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 * NW < NKS) load(ks + 2 * NW, a[0], bq[0]);
+                if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
+                fma_all(a[1], bq[1]);
+                if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks < NKS) fma_all(a[0], bq[0]);
+        };
+        constexpr std::true_type yes{}; constexpr std::false_type no{};
+        if (vc4 == TW / 4) { if (do_bias) k_loop(yes, yes); else k_loop(no, yes); }
+        else { if (do_bias) k_loop(yes, no); else k_loop(no, no); }
     };
 
     const int tile_begin = bx * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
