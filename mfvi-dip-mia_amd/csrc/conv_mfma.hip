@@ -602,69 +602,92 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             auto run_sp = [&](auto steps_c, auto spr_c, auto spc_c, int sbase) {          // STEPS 4-channel steps of the chunk, starting at step sbase
                 constexpr int STEPS = decltype(steps_c)::value, NQ = KK * STEPS;
                 constexpr bool SPR = decltype(spr_c)::value, SPC = decltype(spc_c)::value;
-#ifndef MFMA_STAGES
-#define MFMA_STAGES 2
-#endif
-                constexpr int SG = MFMA_STAGES;
+                constexpr int SG = 2;
                 // Rectangular tiles: a fragment is 16 pixels of ONE row, so the row part of the reflection adjoint moves to the weight operand:
                 //   row 1:   A'(ky=0) = A(ky=0) + A(ky=2)      row H-2:   A'(ky=2) = A(ky=2) + A(ky=0)
                 // (the same products, summed on the A side; the corner term comes out of A' x B').  One extra A read per border-row k-step
                 // instead of up to two extra B reads per fragment; the column part stays on B.
                 constexpr bool AROW = FF && SPR && !FLAT;
-                float a[SG][MF], b[SG][NF], ax[SG], ao[SG][AROW ? MF : 1], axo[SG];
-                auto load = [&](int q, float (&aa)[MF], float (&bb)[NF], float& axx, float (&aoo)[AROW ? MF : 1], float& axoo) {
+                // The k-steps of a stage are ONE straight-line block, software-pipelined at instruction level and pinned with scheduling
+                // barriers: after every MFMA of k-step q, one LDS read of k-step q+1 (into the other register set), so every operand is
+                // requested a whole k-step (MF*NF MFMAs) before its first use and the wave never issues more than one non-matrix instruction
+                // between two MFMAs.  Left to the machine scheduler the reads sank next to their uses (a dozen `s_waitcnt lgkmcnt(0)` per
+                // stage) and the address / wait instructions issued back to back while the matrix pipe drained — harmless with three
+                // consumer waves per SIMD, but 40 % of the matrix rate with one (backward-data at one block per CU; the same change took the
+                // backward-weight kernel from 240 to 198 us).  Reads that patch an operand (reflection adjoint on B) land in their own
+                // registers and are folded in by `finish` at the head of the k-step that uses them.
+                constexpr bool BCOL = FF && SPC, BROW = FF && SPR && FLAT;
+                float a[SG][MF], b[SG][NF], ax[SG], ao[SG][AROW ? MF : 1], axo[SG], e1[SG][BCOL ? NF : 1], e0[SG][BROW ? NF : 1], e2[SG][(BCOL && BROW) ? NF : 1];
+                auto bidx = [&](int f, int st_, int ky, int kx) -> int {
+                    if constexpr (PH) return (sbase + st_) * 4 * PLANE + boff[f] + (((f >> 1) + ky) >> 1) * 24 + (((f & 1) + kx) >> 1);
+                    else if constexpr (FLAT) return (sbase + st_) * 4 * PLANE + boffk[f][ky] + kx;
+                    else return (sbase + st_) * 4 * PLANE + boff[f] + ky * PITCH + kx;
+                };
+                // issue reads number [jlo, jhi) of k-step q into register set s; returns how many reads the k-step has
+                auto load_range = [&](int q, int s_, int jlo, int jhi) -> int {
                     const int tap = q / STEPS, st_ = q % STEPS, ky = tap / KS, kx = tap % KS;
+                    int j = 0;
+                    auto take = [&]() { const bool t_ = j >= jlo && j < jhi; ++j; return t_; };
 #pragma unroll
-                    for (int i = 0; i < MF; ++i) aa[i] = wq[tap * wtap + (sbase + st_) * 4 * CTP + i * 16];
-                    if constexpr (REM) axx = wq[tap * wtap + (sbase + st_) * 4 * CTP + xoff]; else axx = 0.f;
-                    axoo = 0.f;
+                    for (int i = 0; i < MF; ++i) if (take()) a[s_][i] = wq[tap * wtap + (sbase + st_) * 4 * CTP + i * 16];
+                    if constexpr (REM) { if (take()) ax[s_] = wq[tap * wtap + (sbase + st_) * 4 * CTP + xoff]; }
                     if constexpr (AROW) {
                         if (ky != 1) {
                             const int tapo = (2 - ky) * KS + kx;
 #pragma unroll
-                            for (int i = 0; i < MF; ++i) aoo[i] = wq[tapo * wtap + (sbase + st_) * 4 * CTP + i * 16];
-                            if constexpr (REM) axoo = wq[tapo * wtap + (sbase + st_) * 4 * CTP + xoff];
+                            for (int i = 0; i < MF; ++i) if (take()) ao[s_][i] = wq[tapo * wtap + (sbase + st_) * 4 * CTP + i * 16];
+                            if constexpr (REM) { if (take()) axo[s_] = wq[tapo * wtap + (sbase + st_) * 4 * CTP + xoff]; }
                         }
                     }
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        if constexpr (PH) {        // fragment f: row parity (f >> 1) & 1, column parity f & 1
-                            if ((((f >> 1) + ky) & 1) == 0 && (((f & 1) + kx) & 1) == 0)
-                                bb[f] = sx[(sbase + st_) * 4 * PLANE + boff[f] + (((f >> 1) + ky) >> 1) * 24 + (((f & 1) + kx) >> 1)];
-                        } else
-                        bb[f] = FLAT ? sx[(sbase + st_) * 4 * PLANE + boffk[f][ky] + kx] : sx[(sbase + st_) * 4 * PLANE + boff[f] + ky * PITCH + kx];
-                        if constexpr (FF && (SPR || SPC)) {
-                            // adjoint of the reflection padding on the B operand (see the kernel's header); flags are 1.0 on the lanes concerned
-                            auto rd = [&](int ky2, int kx2) -> float {
-                                if constexpr (FLAT) return sx[(sbase + st_) * 4 * PLANE + boffk[f][ky2] + kx2];
-                                else return sx[(sbase + st_) * 4 * PLANE + boff[f] + ky2 * PITCH + kx2];
-                            };
+                    for (int f = 0; f < NF; ++f)
+                        if (!PH || ((((f >> 1) + ky) & 1) == 0 && (((f & 1) + kx) & 1) == 0)) { if (take()) b[s_][f] = sx[bidx(f, st_, ky, kx)]; }
+                    if constexpr (BCOL) {
+                        if (kx != 1) {
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) if (take()) e1[s_][f] = sx[bidx(f, st_, ky, 2 - kx)];
+                        }
+                    }
+                    if constexpr (BROW) {
+                        if (ky != 1) {
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) if (take()) e0[s_][f] = sx[bidx(f, st_, 2 - ky, kx)];
+                        }
+                    }
+                    if constexpr (BCOL && BROW) {
+                        if (ky != 1 && kx != 1) {
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) if (take()) e2[s_][f] = sx[bidx(f, st_, 2 - ky, 2 - kx)];
+                        }
+                    }
+                    return j;
+                };
+                // adjoint of the reflection padding on the B operand (see the kernel's header); flags are 1.0 on the lanes concerned
+                auto finish = [&](int q, int s_) {
+                    if constexpr (BCOL || BROW) {
+                        const int tap = q / STEPS, ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
                             int rowf, colf;
                             if constexpr (FLAT) { rowf = tpy0 + (frc[f] >> 16); colf = frc[f] & 0xffff; }
                             else { rowf = tpy0 + wv * (TH / 4) + (f >> 1); colf = tpx0 + (f & 1) * 16 + l15; }
-                            const float fr = (SPR && FLAT && ky != 1 && rowf == (ky == 2 ? 1 : g.H - 2)) ? 1.f : 0.f;
-                            const float fc = (SPC && kx != 1 && colf == (kx == 2 ? 1 : g.W - 2)) ? 1.f : 0.f;
+                            const float fr = (BROW && ky != 1 && rowf == (ky == 2 ? 1 : g.H - 2)) ? 1.f : 0.f;
+                            const float fc = (BCOL && kx != 1 && colf == (kx == 2 ? 1 : g.W - 2)) ? 1.f : 0.f;
                             float e = 0.f;
-                            if constexpr (SPR && FLAT) { if (ky != 1) e = __builtin_fmaf(fr, rd(2 - ky, kx), e); }
-                            if constexpr (SPC) { if (kx != 1) e = __builtin_fmaf(fc, rd(ky, 2 - kx), e); }
-                            if constexpr (SPR && SPC && FLAT) { if (ky != 1 && kx != 1) e = __builtin_fmaf(fr * fc, rd(2 - ky, 2 - kx), e); }
-                            bb[f] += e;
+                            if constexpr (BROW) { if (ky != 1) e = __builtin_fmaf(fr, e0[s_][f], e); }
+                            if constexpr (BCOL) { if (kx != 1) e = __builtin_fmaf(fc, e1[s_][f], e); }
+                            if constexpr (BCOL && BROW) { if (ky != 1 && kx != 1) e = __builtin_fmaf(fr * fc, e2[s_][f], e); }
+                            b[s_][f] += e;
                         }
                     }
                 };
-#ifndef MFVI_FENCE
-#define MFVI_FENCE 0
-#endif
-                // MFVI_FENCE=1: scheduling fences keep the software pipeline as written — operands of k-step q + 1 requested, THEN the MFMAs of
-                // k-step q.  Without them the machine scheduler pulls each ds_read down next to its first use (fewer live registers) and a wave
-                // sits in `s_waitcnt lgkmcnt(0)` a dozen times per stage.  Measured on MI355X (profiles/r02_fence_ab.txt): no difference, the
-                // other two consumer waves of the SIMD fill those gaps — kept as an A/B switch.
-#pragma unroll
-                for (int q = 0; q < SG - 1; ++q) if (q < NQ) load(q, a[q % SG], b[q % SG], ax[q % SG], ao[q % SG], axo[q % SG]);
+                load_range(0, 0, 0, 1 << 20);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    if (q + SG - 1 < NQ) load(q + SG - 1, a[(q + SG - 1) % SG], b[(q + SG - 1) % SG], ax[(q + SG - 1) % SG], ao[(q + SG - 1) % SG], axo[(q + SG - 1) % SG]);
-                    if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
+                    const int s_ = q % SG, sn = (q + 1) % SG;
+                    const int n_next = q + 1 < NQ ? load_range(q + 1, sn, 0, 0) : 0;
+                    int m = 0;
+                    finish(q, s_);
                     const int tapq = q / STEPS, kyq = tapq / KS, kxq = tapq % KS;
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
@@ -674,19 +697,23 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
 #pragma unroll
                         for (int i = 0; i < MF; ++i)
                             if (!PH || ((((f >> 1) + kyq) & 1) == 0 && (((f & 1) + kxq) & 1) == 0)) {
-                                float av = a[q % SG][i];
-                                if constexpr (AROW) { if (kyq != 1) av = __builtin_fmaf(frw, ao[q % SG][i], av); }
-                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q % SG][f], acc[i][f], 0, 0, 0);
+                                float av = a[s_][i];
+                                if constexpr (AROW) { if (kyq != 1) av = __builtin_fmaf(frw, ao[s_][i], av); }
+                                if (m < n_next) load_range(q + 1, sn, m, m + 1);
+                                ++m;
+                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s_][f], acc[i][f], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
                             }
                         if constexpr (REM) {
-                            if (rem_blk) {
-                                float av = ax[q % SG];
-                                if constexpr (AROW) { if (kyq != 1) av = __builtin_fmaf(frw, axo[q % SG], av); }
-                                accx[f] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, b[q % SG][f], accx[f], 0, 0, 0);
-                            }
+                            float av = ax[s_];
+                            if constexpr (AROW) { if (kyq != 1) av = __builtin_fmaf(frw, axo[s_], av); }
+                            if (m < n_next) load_range(q + 1, sn, m, m + 1);
+                            ++m;
+                            if (rem_blk) accx[f] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, b[s_][f], accx[f], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (MFVI_FENCE) __builtin_amdgcn_sched_barrier(0);
+                    if (m < n_next) load_range(q + 1, sn, m, 1 << 20);
                 }
             };
             auto run = [&](auto steps_c, int sbase) {          // border tiles take the variant with the reflected rows / columns they hold
