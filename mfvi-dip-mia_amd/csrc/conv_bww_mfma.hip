@@ -298,8 +298,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
                         float e[4] = {pgr[i][j].x, pgr[i][j].y, pgr[i][j].z, pgr[i][j].w};
                         if (yp) {
                             const float yy[4] = {pyr[i][j].x, pyr[i][j].y, pyr[i][j].z, pyr[i][j].w};
-#pragma unroll
-                            for (int l = 0; l < 4; ++l) e[l] = apply_bwd(cgk, e[l], yy[l]);
+                            apply_bwd4(cgk, e, yy);
                         }
                         if (pgo[j] < 0 || c >= cot) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
                         if (64 * (j + 1) <= NGI || q < NGI) lds_store4(s_g + c * GPLANE + 4 * q, e[0], e[1], e[2], e[3]);
@@ -313,8 +312,8 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
                     for (int j = 0; j < NPX; ++j) {
                         const int q = lane + 64 * j, flag = pxo[j] & 3;
                         float e[4] = {pxr[i][j].x, pxr[i][j].y, pxr[i][j].z, pxr[i][j].w};
-#pragma unroll
-                        for (int l = 0; l < 4; ++l) e[l] = c < cit ? apply_fwd(cx, e[l], in.act, in.slope) : 0.f;
+                        apply_fwd4(cx, e, in.act, in.slope);
+                        if (c >= cit) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
                         if (flag == 1) e[3] = e[1];                       // column -1 <- x[1]
                         else if (flag == 2) e[0] = e[2];                  // column W  <- x[W-2]
                         if (64 * (j + 1) <= NXI || q < NXI) lds_store4(s_x + c * XPLANE + 4 * q, e[0], e[1], e[2], e[3]);

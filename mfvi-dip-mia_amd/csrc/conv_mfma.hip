@@ -398,15 +398,13 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
                     const int flag = voff[j] & 3;
                     float e[4] = {xv[i][j].x, xv[i][j].y, xv[i][j].z, xv[i][j].w};
                     if (MODE == 0) {
-#pragma unroll
-                        for (int l = 0; l < 4; ++l) e[l] = apply_fwd(kf, e[l], xact, xslope);
+                        apply_fwd4(kf, e, xact, xslope);
                         if (flag == 1) { e[3] = e[1]; }                      // column -1 <- x[1]   (columns -4..-2 are never read)
                         else if (flag == 2) { e[0] = e[2]; }                 // column W  <- x[W-2] (columns W+1.. only feed masked outputs)
                     } else {
                         if (ysrc) {
                             const float yy[4] = {yv[i][j].x, yv[i][j].y, yv[i][j].z, yv[i][j].w};
-#pragma unroll
-                            for (int l = 0; l < 4; ++l) e[l] = apply_bwd(kb, e[l], yy[l]);
+                            apply_bwd4(kb, e, yy);
                         }
                         if (stuffed) { e[1] = 0.f; e[3] = 0.f; }
                     }

@@ -100,6 +100,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         if (ti.d.has_act && !ti.d.has_bn) return fail("plan: tensor %d: activation without BatchNorm is not part of the skip() family", i);
         if (ti.d.has_bn && (ti.d.bn_off < 0 || ti.d.bn_off + 2LL * ti.d.C > p.n_bn)) return fail("plan: tensor %d: bn_off out of range", i);
         if (!(ti.d.drop_p >= 0.f && ti.d.drop_p < 1.f)) return fail("plan: tensor %d: dropout probability %g outside [0, 1)", i, (double)ti.d.drop_p);
+        if (ti.d.has_act && !(ti.d.slope >= 0.f && ti.d.slope <= 1.f)) return fail("plan: tensor %d: LeakyReLU slope %g outside [0, 1] (the kernels form it as max(v, slope * v))", i, (double)ti.d.slope);
         if (ti.d.drop_p > 0.f && !ti.d.has_bn) return fail("plan: tensor %d: Dropout2d without a following BatchNorm is not part of the skip() family", i);
         ti.numel = (long long)ti.d.C * ti.d.H * ti.d.W;
     }

@@ -34,7 +34,7 @@ rep('''            __syncthreads();                                             
             for (int tile = tile_begin; tile < tile_end; ++tile) {
                 if (tile > tile_begin) __syncthreads();                  // (B1)
                 __syncthreads();                                         // (B2)
-                mfma_tile();
+                mfma_tile(tile);
             }''', '''            __syncthreads();                                             // (S0)
             TICK(0)
             for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -42,7 +42,7 @@ rep('''            __syncthreads();                                             
                 TICK(2)
                 __syncthreads();                                         // (B2)
                 TICK(4)
-                mfma_tile();
+                mfma_tile(tile);
                 TICK(5)
             }''')
 rep("    // ---- sum the MFMA waves through LDS", "    TICK(6)\n    // ---- sum the MFMA waves through LDS")
