@@ -638,7 +638,11 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         if (o.d.type == MFVI_OP_CONV) {
             const GView gy = c.gview(o.d.out, dout);
             const TView xin = c.view(o.d.in0);
-            sw = ((long long)o.g.Ho * o.g.Wo <= side_maxpix) ? side : st;
+            // Layers that read the network input have no backward-data (unless dz is asked for): their backward-weight kernel is all the
+            // caller's stream would do for them, so it runs there — at the end of the pass the side stream is still working off the last
+            // layers' kernels while the caller's stream would sit idle (a ~100 us tail of three serial launches otherwise).
+            const bool bww_only = (o.d.in0 == plan->input) && dz == nullptr;
+            sw = (!bww_only && (long long)o.g.Ho * o.g.Wo <= side_maxpix) ? side : st;
             if (sw != st) {      // fork: everything this layer's backward-weight reads (dy, BN-backward sums) is final at this point of `st`
                 if (n_fork == plan->fork_events.size()) {
                     hipEvent_t ev; const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
