@@ -131,13 +131,15 @@ int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* o
 
 /* Optional, once per plan: run one forward + backward, then time every valid MFMA tiling (output-channel fragments x tile
  * rows x tiles per block) of every conv op's forward, backward-data and backward-weight kernel with HIP events on `stream` and keep the
- * fastest per (op, pass).  Tilings do not change any result (same accumulation order per output element).
+ * fastest per (op, pass).  Tilings do not change the forward result (same accumulation order per output element); gradients agree to
+ * summation-order rounding (partial sums per pixel strip, the 4x4x1 variant below).
  * out_scratch: 2 * n_samples * numel(output tensor) floats; grad_scratch: 2 * n_vi + n_bn floats.  Synchronises `stream`.
  * Contents of workspace / scratch are undefined afterwards.  MFVI_AUTOTUNE=0 in the environment makes this a no-op. */
 int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const float* bn, const float* z, int n_samples,
                        void* workspace, float* out_scratch, float* grad_scratch, void* stream);
-/* Tiling in use for conv op `op`: which 0 forward, 1 backward-data (mf | th << 8 | T << 16), 2 backward-weight
- * (input tiles | waves << 8 | block target/256 << 16); 0 = built-in heuristic. */
+/* Tiling in use for conv op `op`: which 0 forward, 1 backward-data (mf | th << 8 | T << 16; th bit 128 = tiles of whole rows for
+ * narrow maps, th bit 64 (backward-data of layers with 16n + 4 input channels) = the last 4 channels on the 4x4x1 matrix instruction
+ * instead of a padded 16-channel fragment), 2 backward-weight (input tiles | waves << 8 | block target/256 << 16); 0 = built-in heuristic. */
 int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which);
 int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
 
