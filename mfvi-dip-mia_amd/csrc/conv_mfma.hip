@@ -113,7 +113,7 @@ struct MfmaArgs {
 // lanes of the 16x16x4 pixel fragment already in registers, against A = w[extra channel lane & 3][k = lane >> 4] — 8 cycles instead of
 // a 32-cycle fragment.  Each lane accumulates its own k-slice; the four slices are added across lanes (l15 + 16*l4) in the epilogue.
 template <int KS, int STRIDE, int MF, int TH, int MODE, bool WS, bool FLAT, bool BIGC = false, bool PH = false, bool FF = false, bool REM = false>
-__global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= (REM ? 8 : 16) ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
+__global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 16 ? 4 : (MF * TH <= 32 ? 2 : 1)))) void conv_mfma_kernel(MfmaArgs A)
 {
     static_assert(!PH || (MODE == 1 && KS == 3 && !FLAT && !BIGC), "phase decomposition: 3x3 backward-data on rectangular tiles");
     static_assert(!FF || (MODE == 1 && KS == 3 && STRIDE == 1 && !PH), "fused fold: 3x3 stride-1 backward-data");
@@ -138,8 +138,6 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     // other half of a double buffer.  One barrier per chunk; VALU/VMEM work hides under the matrix pipe.
     extern __shared__ __align__(16) float s_w[];          // WS: [KK][REDP][CTP]; else 2 x [KK][CC][CTP]
     __shared__ __align__(16) float s_x[2][Cfg::X_FLOATS];
-    __shared__ ChanFwd s_ch[(MODE == 0 || KS == 1 || FF) ? MFVI_MAX_C : 1];
-    __shared__ ChanBwd s_chb[MODE == 1 ? MFVI_MAX_C : 1];
     __shared__ float s_bias[CT];
     __shared__ double s_red[4][CTX][2];
     __shared__ __align__(16) float s_ep[(FLAT || PEPI) ? 1 : 4][(FLAT || PEPI) ? 1 : 16][(FLAT || PEPI) ? 4 : EPP];    // rectangular tiles: epilogue transpose, one slab per consumer wave
@@ -164,6 +162,11 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     const int n_chunks = (RED + CC - 1) / CC;
 
     const float* __restrict__ wk = A.w + (long long)k * A.wstride;
+    // per-channel constants of the input view (ChanFwd[Cin]) and of the gradient view (ChanBwd[Cout]) live in dynamic LDS behind the weights,
+    // sized by the layer (static MFVI_MAX_C-sized tables cost 9 KB per block — the difference between one and two blocks per CU for the
+    // fused backward-data kernel with its out tile)
+    ChanFwd* __restrict__ s_ch = reinterpret_cast<ChanFwd*>(s_w + (WS ? KK * REDP * CTP : 2 * WCHUNK));
+    ChanBwd* __restrict__ s_chb = reinterpret_cast<ChanBwd*>(s_ch + ((g.Cin + 3) & ~3));
 
     if (MODE == 0) {
         for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c);
@@ -717,7 +720,10 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
             auto run = [&](auto steps_c, int sbase) {          // border tiles take the variant with the reflected rows / columns they hold
                 constexpr std::false_type no{}; constexpr std::true_type yes{};
                 if constexpr (FF) {
-                    if (spr && spc) run_sp(steps_c, yes, yes, sbase);
+                    // rectangular tiles: ONE block of code with the border patches always woven in (flags are zero in interior tiles; the four
+                    // separately unrolled variants cost ~60 VGPRs of live state between them and the second block per CU with it)
+                    if constexpr (!FLAT) run_sp(steps_c, yes, yes, sbase);
+                    else if (spr && spc) run_sp(steps_c, yes, yes, sbase);
                     else if (spr) run_sp(steps_c, yes, no, sbase);
                     else if (spc) run_sp(steps_c, no, yes, sbase);
                     else run_sp(steps_c, no, no, sbase);
@@ -1045,6 +1051,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
     for (int i = 1; i < 4; ++i) for (int j = i; j > 0 && cost(order[j]) < cost(order[j - 1]); --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
     const long long want = 768;
     int forced_T = 0;
+    const size_t chan_bytes = sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(ChanBwd) * (size_t)((g.Cout + 3) & ~3);   // dynamic LDS behind the weights
     bool want_rem = false;      // tune bit 64 of the tile-height field: carry the layer's last 4 output channels on the 4x4x1 matrix instruction
 #define GO_(MF_, TH_, FL_)                                                                                                 \
     {                                                                                                                      \
@@ -1084,24 +1091,24 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (lds_big + ws_bytes > 150 * 1024) big = false;                                                              \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
-            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
-            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
-            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
-            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
-            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes, st, A); \
+            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
         } else {                                                                                                           \
             if (forced_T > 1) return -3;                                                                                   \
             if (lds_big + ck_big > 150 * 1024) big = false;                                                                \
             if (big) ck_bytes = ck_big;                                                                                    \
             A.tiles_per_block = 1;                                                                                         \
             A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
-            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
-            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
-            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
-            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
-            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
-            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes, st, A); \
+            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }
