@@ -1098,11 +1098,14 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
             else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
         } else {                                                                                                           \
-            if (forced_T > 1) return -3;                                                                                   \
+            /* chunked weights: one tile per block, except for the fused fold on rectangular tiles, whose producer-side fold of tile i   \
+               overlaps the stages of tile i+1 (the weights of a stage are re-read from L2 per tile) */                                   \
+            const bool multi = ff && !(FL_);                                                                               \
+            if (forced_T > 1 && !multi) return -3;                                                                         \
             if (lds_big + ck_big > 150 * 1024) big = false;                                                                \
             if (big) ck_bytes = ck_big;                                                                                    \
-            A.tiles_per_block = 1;                                                                                         \
-            A.nx = A.n_tiles; A.ny = my; A.nz = n_samples;                                                                 \
+            A.tiles_per_block = multi ? T : 1;                                                                             \
+            A.nx = (A.n_tiles + A.tiles_per_block - 1) / A.tiles_per_block; A.ny = my; A.nz = n_samples;                   \
             if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
             else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
             else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
