@@ -80,6 +80,9 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     const int Cin = g.Cin, Cout = g.Cout, H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
     const bool do_bias = (ci0 == 0) && (g.b_off >= 0);
     const int cot = min(16, Cout - co0), cit = min(CIB, Cin - ci0);
+    // 4-channel remainder group on the 4x4x1 matrix instruction: full-width tiles of the specialised / 4-wave variants only (the others keep
+    // the padded fragment); decided per tile below, the epilogue follows `x4_used`
+    const bool x4_blk = NB == 1 && NW == 4 && ci0 > 0 && cit <= 4 && Wo % TW == 0;
 
     if (t < CIB) s_chx[t] = chan_fwd(in, k, min(ci0 + t, Cin - 1));
     if (t >= 64 && t < 80) s_chg[t - 64] = chan_bwd(gy, k, min(co0 + t - 64, Cout - 1));
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
         // that order (every operand is requested a full k-step = 9*NB MFMAs before its use).  Written as "all reads of i+1, fence, all
         // MFMAs of i" (the generic path below) the ~30 non-matrix instructions of a k-step issue back to back while the matrix pipe
         // drains (in-order issue): 40 % of the pipe's rate inside the MFMA phase.
-        auto k_loop = [&](auto bias_c, auto fullw_c) {
-            constexpr bool BIAS = decltype(bias_c)::value, FULLW = decltype(fullw_c)::value;
+        auto k_loop = [&](auto bias_c, auto fullw_c, auto x4_c) {
+            constexpr bool BIAS = decltype(bias_c)::value, FULLW = decltype(fullw_c)::value, X4 = decltype(x4_c)::value;
             float a[2], bq[2][NOP];
             auto load = [&](int ks, float& aa, float (&bb)[NOP]) {
                 const int row = ks / vc4, c4 = (ks - row * vc4) * 4;
@@ -200,13 +203,17 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
                                 const int q = b * KK + ky * KS + kx;
                                 bn[q] = xp[b * 16 * XPLANE + ky * WV + kx];
                                 if (q == 0) an = gp[0];
-                                acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[q], acc[b][ky * KS + kx], 0, 0, 0);
+                                if constexpr (X4) acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(aa, bb[q], acc[b][ky * KS + kx], 0, 0, 0);
+                                else acc[b][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[q], acc[b][ky * KS + kx], 0, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                     if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, 1.0f, accb, 0, 0, 0);
                 };
                 const float* ga = s_g + l15 * GPLANE + wv * 4 + l4;
-                const float* xa = s_x + l15 * XPLANE + (wv * 4 + l4) * STRIDE + XOFF;
+                // X4: the block's input-channel group holds only the layer's last 4 channels (36 / 68 / 132 = 16n + 4): 16 independent 4x4 outer
+                // products per instruction (v_mfma_f32_4x4x1: block b = lane >> 2 pairs dy[co = 4*(b & 3) + i][pixel slice b >> 2], the lanes of
+                // the ordinary A fragment, with x[pixel][channel lane & 3]) — 8 cycles per tap instead of a 32-cycle fragment with 12 empty columns
+                const float* xa = s_x + (X4 ? (l15 & 3) : l15) * XPLANE + (wv * 4 + l4) * STRIDE + XOFF;
                 a[0] = ga[0];
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             if (ks < NKS) fma_all(a[0], bq[0]);
         };
         constexpr std::true_type yes{}; constexpr std::false_type no{};
-        if (vc4 == TW / 4) { if (do_bias) k_loop(yes, yes); else k_loop(no, yes); }
-        else { if (do_bias) k_loop(yes, no); else k_loop(no, no); }
+        if (vc4 == TW / 4) { if (x4_blk) k_loop(no, yes, yes); else if (do_bias) k_loop(yes, yes, no); else k_loop(no, yes, no); }
+        else { if (do_bias) k_loop(yes, no, no); else k_loop(no, no, no); }
     };
 
     const int tile_begin = bx * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
                     int gx = ax0 + 4 * v, flag = 0;
                     if (gx < 0) { flag = 1; gx = 0; } else if (gx >= W) { flag = gx == W ? 2 : 0; gx = W - 4; }
                     pxo[j] = (gyy * W + gx) | flag;
+                    if (pw * CPW >= cit) continue;          // this wave's input channels lie beyond the layer (4-channel remainder group): nothing to stage
 #pragma unroll
                     for (int i = 0; i < CPW; ++i)
                         pxr[i][j] = *reinterpret_cast<const float4*>(xin + (long long)(ci0 + min(pw * CPW + i, cit - 1)) * HW + (pxo[j] & ~3));
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
 #pragma unroll
                 for (int i = 0; i < CPW; ++i) {
                     const int c = pw * CPW + i;
+                    if (x4_blk && pw * CPW >= cit) break;          // the 4x4x1 path reads channels 0..3 only
                     const ChanFwd cx = s_chx[c];
 #pragma unroll
                     for (int j = 0; j < NPX; ++j) {
@@ -356,6 +365,16 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     float* s_db = lds + 4 * 16 * ROWP;      // [4][16]         bias-gradient partials
     const int rw = wv & 3;
     auto put = [&](bool add) {
+        if (x4_blk) {       // 4x4x1 accumulators: lane 4b + j, register i = dW[co = 4*(b & 3) + i][ci = j] of pixel slice b >> 2: add the four slices first
+#pragma unroll
+            for (int q = 0; q < KK; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[0][q][r]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                    if (lane < 16) s_ep[(rw * 16 + 4 * (lane >> 2) + r) * ROWP + (lane & 3) * KK + q] = v;
+                }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
