@@ -31,6 +31,8 @@ class Program:
         t = self.tensors[tid]
         if t["has_bn"]:
             raise ValueError("tensor %d already has a BatchNorm" % tid)
+        if act and not 0.0 <= slope <= 1.0:          # the kernels form LeakyReLU as max(v, slope * v) (mfvi_plan_create checks it too)
+            raise ValueError("LeakyReLU slope %r outside [0, 1]" % (slope,))
         t.update(has_bn=1, has_act=int(act), slope=slope, eps=eps, bn_off=self.n_bn)
         self.bns.append(dict(C=t["C"], off=self.n_bn, tensor=tid))
         self.n_bn += 2 * t["C"]

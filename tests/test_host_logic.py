@@ -66,6 +66,9 @@ def test_program_layout_and_unsupported_options():
     conv, bn, n_vi, n_bnp = O.net_table(O.make_net(64, 64))
     assert (P.n_vi, P.n_bn) == (n_vi, n_bnp) == (1035446, 3984)
     assert [(l["w_off"], l["b_off"]) for l in P.layers] == [(int(c[4]), int(c[5])) for c in conv]
+    Q = M.Program(); tq = Q.tensor(4, 8, 8)
+    with pytest.raises(ValueError):
+        Q.set_bn(tq, act=True, slope=1.5)            # LeakyReLU is formed as max(v, slope * v): slopes outside [0, 1] are refused
     with pytest.raises(NotImplementedError):
         M.skip(16, 2, need_sigmoid=True, pad='reflection', upsample_mode='bilinear')
     with pytest.raises(NotImplementedError):
