@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     const int cot = min(16, Cout - co0), cit = min(CIB, Cin - ci0);
     // 4-channel remainder group on the 4x4x1 matrix instruction: full-width tiles of the specialised / 4-wave variants only (the others keep
     // the padded fragment); decided per tile below, the epilogue follows `x4_used`
-    const bool x4_blk = NB == 1 && NW == 4 && ci0 > 0 && cit <= 4 && Wo % TW == 0;
+    const bool x4_blk = KS <= 3 && NB == 1 && NW == 4 && ci0 > 0 && cit <= 4 && Wo % TW == 0;
 
     if (t < CIB) s_chx[t] = chan_fwd(in, k, min(ci0 + t, Cin - 1));
     if (t >= 64 && t < 80) s_chg[t - 64] = chan_bwd(gy, k, min(co0 + t - 64, Cout - 1));
