@@ -363,7 +363,7 @@ def _run_plan(plan, P, seed, n, z, dout):
     return host(o), host(dmu), host(drho), host(dz)
 
 
-@pytest.mark.parametrize("shape", [(36, 16, 64, 64), (68, 32, 32, 32), (132, 64, 16, 16)])
+@pytest.mark.parametrize("shape", [(36, 16, 64, 64), (68, 32, 32, 32), (132, 64, 16, 16), (36, 16, 40, 80)])
 def test_tilings_do_not_change_results(M, shape):
     """Every tiling the autotuner may pick (rectangular / FLAT tiles, fragments, tiles per block, backward-weight variants)
     computes the same numbers: forward bit-identical, gradients to summation-order rounding."""
