@@ -58,6 +58,8 @@ CONV_CASES = [
     (16, 4, 1, 1, 12, 12), (16, 16, 3, 2, 16, 16), (16, 16, 3, 1, 10, 14), (36, 16, 3, 1, 8, 8), (8, 32, 3, 2, 12, 20),
     (32, 2, 1, 1, 6, 6), (132, 8, 3, 1, 8, 8), (5, 3, 3, 1, 33, 47), (7, 21, 3, 2, 18, 70), (3, 19, 1, 1, 40, 36),
     (128, 128, 3, 1, 2, 2), (16, 16, 3, 1, 64, 64), (12, 20, 3, 2, 2, 2),
+    # several rectangular tiles with a partial last tile column / row: fused fold by the producer waves, border patches in every position
+    (36, 16, 3, 1, 40, 80), (68, 32, 3, 1, 24, 96), (20, 16, 3, 1, 36, 44),
     # stride 2 with Wo % 4 == 0 (phase-decomposed backward-data): tiny, ragged and multi-tile domains
     (16, 16, 3, 2, 8, 8), (32, 32, 3, 2, 8, 24), (16, 24, 3, 2, 72, 40), (64, 16, 3, 2, 24, 136),
     # 5x5 filters of the inpainting variant (bayesian_optimization.py:2970-2998): reflection pad 2, stride 1 and 2
