@@ -413,6 +413,9 @@ def main(argv=None):
     ap.add_argument("--devices", default=None, help="comma-separated devices (cuda:0,cuda:1,...): the independent fits are dealt round-robin to one "
                                                     "fresh worker process per device (default: the config's run_params.devices; absent: this process)")
     ap.add_argument("--param-dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--bo-rounds", type=int, default=0, help="> 0: the reference's Gaussian-process outer loop over the method's two hyper-parameters "
+                                                             "(bo_params.<name>.logbounds of the config) for this many rounds, each round's candidates "
+                                                             "run as independent fits (bo.py; parity unpinned: gpytorch is not available here)")
     a = ap.parse_args(argv)
     cands, rp, cfg_devices = load_config(a.config, a.bayes, with_devices=True)
     short = {"denoising": "den", "super-resolution": "sr", "ct": "ct", "inpainting": "inp"}[a.task]
@@ -433,6 +436,22 @@ def main(argv=None):
     rp.pop("img", None)
     jobs = [dict(cand, img=im) for im in imgs for cand in cands]
     devices = a.devices.split(",") if a.devices else cfg_devices
+    if a.bo_rounds > 0:
+        # bo() of the reference (bayesian_optimization.py:3727-3880): rounds of [fits of the candidates over the devices -> GP -> new candidates]
+        from . import bo as _bo
+        keys = BO_KEYS[a.bayes]
+        if not keys or len(imgs) != 1:
+            raise ValueError("--bo-rounds needs a method with two hyper-parameters (mfvi, mcd, sgld) and one image")
+        bo_params = {k: json.load(open(a.config))["bo_params"][k] for k in keys}
+
+        def evaluate(cand_list):
+            jb = [dict(zip(keys, c), img=imgs[0]) for c in cand_list]
+            if devices:
+                from .fanout import run_jobs
+                res, _ = run_jobs(jb, devices, "mfvi_dip_mia_amd.runner:fit_job", dict(rp, fn_name=fn_name, K=a.k))
+                return [(tuple(job[k] for k in keys), y) for _, job, y in res]
+            return [(c, fn(K=a.k, verbose=False, **j, **rp)["psnr"]) for c, j in zip(cand_list, jb)]
+        return _bo.bo(bo_params, evaluate, n_rounds=a.bo_rounds)
     if devices:
         # independent fits over the node's GPUs (bayesian_optimization.py:3760-3781, eval_result.py:27-53): no per-step communication,
         # one final gather of (candidate, psnr), NaNs dropped

@@ -152,3 +152,20 @@ def test_sibling_runners_other_tasks(M, tmp_path):
     ps = z["psnrs"].item()["dip"]
     assert ps.shape == (41, 3) and np.isfinite(ps).all() and ps[-1, 2] > ps[3, 2] and z["uncerts"].item() == {}
     assert r["engine"].weight_decay == 0.0
+
+
+@pytest.mark.gpu
+def test_cli_gp_outer_loop_two_rounds(M, tmp_path, capsys):
+    """`--bo-rounds 2` of the runner CLI: round 0 fits the config's candidates, the GP (bo.py, parity unpinned) proposes new
+    (temp, sigma) pairs inside the config's log bounds, round 1 fits those through the same HIP path — every fit returns a finite PSNR."""
+    import json
+    cfg = {"bo_params": {"temp": {"logbounds": [-8.0, -5.0], "candidates": [5.66e-7, 5e-6]}, "sigma": {"logbounds": [-6.0, -4.0], "candidates": [1.46e-5]}},
+           "run_params": {"img": "phantom", "num_iter": 12, "lr": 1e-3, "seed": 1, "p_sigma": 0.1, "input_depth": 16, "show_every": 4, "plot": False,
+                          "save": False, "save_path": str(tmp_path)}}
+    path = os.path.join(str(tmp_path), "bo_den.json")
+    json.dump(cfg, open(path, "w"))
+    X, Y, nxt = M.runner.main(["--task", "denoising", "--bayes", "mfvi", "--config", path, "--imsize", "64", "--k", "2", "--bo-rounds", "2"])
+    assert len(X) == len(Y) >= 3 and all(np.isfinite(y) for y in Y)          # 2 fits in round 0, >= 1 proposal in round 1
+    for t, s in list(X[2:]) + list(nxt):
+        assert 1e-8 * (1 - 1e-9) <= t <= 1e-5 * (1 + 1e-9) and 1e-6 * (1 - 1e-9) <= s <= 1e-4 * (1 + 1e-9)
+    assert "psnr" in capsys.readouterr().out

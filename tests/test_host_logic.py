@@ -227,3 +227,59 @@ def test_artifacts_open_in_the_reference_notebooks(tmp_path, task, method):
     assert want <= set(os.listdir(run_dir))
     txt = open(os.path.join(run_dir, "locals.txt")).read()
     assert "%s PSNR_max" % method in txt and "%s SSIM_max" % method in txt and "num_iter = 300" in txt
+
+
+def test_gp_outer_loop_restatement():
+    """bo.py restates the reference's GP outer loop (bayesian_optimization.py:3545-3880) without gpytorch / skimage — parity unpinned, so
+    the checks are the model's own properties: initial hyper-parameters as gpytorch sets them, the posterior interpolating its training
+    points, EI >= 0 and ~0 where the mean is low and certain, the peak finder's exclusion rules, candidates inside [0, 1]^2, the box
+    normalisation, and the loop improving a synthetic objective through the candidate -> evaluate -> refit cycle."""
+    import math
+    import torch
+    from mfvi_dip_mia_amd import bo as B
+    torch.manual_seed(0)
+    X = torch.rand(12, 2, dtype=torch.float64)
+    f = lambda x: 20.0 + 5.0 * torch.exp(-((x - torch.tensor([0.7, 0.3])) ** 2).sum(-1) / 0.05)
+    Y = f(X)
+    gp0 = B.ExactGP(X, Y)
+    assert abs(gp0.lengthscale.item() - 0.3) < 1e-12 and abs(gp0.outputscale.item() - math.log(2)) < 1e-12
+    assert abs(gp0.noise.item() - (math.log(2) + 1e-4)) < 1e-12 and gp0.raw_mean.item() == 0.0
+    l0 = gp0.neg_mll().item()
+    gp = B.train_gp(X, Y, iter_max=1200)
+    assert gp.neg_mll().item() < l0                                   # Adam on the marginal likelihood made progress
+    mu, var = gp.posterior(X)
+    assert (mu - Y).abs().max().item() < 0.1 and (var >= -1e-9).all() and gp.noise.item() < 0.01     # noise-free data: the fit interpolates
+    g = torch.linspace(0, 1, 100, dtype=torch.float64)
+    G1, G2 = torch.meshgrid(g, g, indexing="ij")
+    grid = torch.stack([G1.reshape(-1), G2.reshape(-1)]).transpose(1, 0)
+    ei = B.expected_improvement(gp, grid, X)
+    assert ei.shape == (10000, 1) and (ei >= 0).all() and ei.max().item() > 0
+    ucb = B.upper_confidence_bound(gp, grid)
+    assert ucb.shape == (10000,)
+    # peak finder: two separated bumps and one inside the excluded border
+    img = np.zeros((40, 40)); img[10, 12] = 5.0; img[30, 25] = 3.0; img[2, 2] = 9.0; img[11, 13] = 4.0; img[20, 20] = 0.2
+    pk = B.peak_local_max(img, min_distance=5, threshold_rel=0.1, num_peaks=4)
+    assert [tuple(p) for p in pk] == [(10, 12), (30, 25)]
+    cands, imp, acq = B.find_candidates(gp, grid, X)
+    assert acq.shape == (100, 100) and 1 <= len(cands) <= 4 and len(imp) == len(cands)
+    for c in cands:
+        assert c.shape == (1, 2) and (c >= 0).all() and (c <= 1).all()
+    Xn = B.normalize_X(torch.tensor([[1e-3, 1e-5]], dtype=torch.float64), [-4.0, -2.0], [-6.0, -4.0])
+    assert torch.allclose(Xn, torch.tensor([[(1e-3 + 4.0) / 2.0, (1e-5 + 6.0) / 2.0]], dtype=torch.float64))
+    assert torch.allclose(B.unnormalize_X(Xn, [-4.0, -2.0], [-6.0, -4.0]), torch.tensor([[1e-3, 1e-5]], dtype=torch.float64))
+    # the loop on a synthetic objective; one candidate fails (NaN) in every round and must be dropped
+    calls = []
+
+    def evaluate(cl):
+        calls.append(list(cl))
+        out = []
+        for i, (a, b) in enumerate(cl):
+            y = 25.0 - 40.0 * ((math.log10(a) + 3.0) ** 2 + (math.log10(b) + 5.0) ** 2) if i != 1 else float("nan")
+            out.append(((a, b), y))
+        return out
+    bo_params = {"temp": {"logbounds": [-4.0, -2.0], "candidates": [1e-4, 1e-2]}, "sigma": {"logbounds": [-6.0, -4.0], "candidates": [1e-6, 1e-4]}}
+    Xh, Yh, nxt = B.bo(bo_params, evaluate, n_rounds=2, gp_iters=150, verbose=False)
+    assert len(calls) == 2 and len(calls[0]) == 4 and len(Xh) == len(Yh) == 3 + len(calls[1]) - (1 if len(calls[1]) > 1 else 0)
+    assert all(not math.isnan(y) for y in Yh) and len(nxt) >= 1
+    for a, b in nxt:                                                  # proposals stay inside the log-bounds box
+        assert 1e-4 * (1 - 1e-9) <= a <= 1e-2 * (1 + 1e-9) and 1e-6 * (1 - 1e-9) <= b <= 1e-4 * (1 + 1e-9)
