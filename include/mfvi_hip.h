@@ -63,7 +63,9 @@ typedef struct {
  *                    eps ~ N(0,1) in OUTPUT space: element j of [Cout][Ho][Wo] = lane j & 3 of block j >> 2 of RNG domain 7, stream
  *                    layer_id.  sample_weights = 0: out = conv2d(v, mu, mu_b) (LRTLayer's eval branch).  Same parameters, same KL.
  * MFVI_OP_CONCAT_UP  out = cat(view(in0), upsample2x_bilinear(view(in1)))  (in0 = -1: upsample only)
- *                    = Concat + nn.Upsample: models/common.py:23-43, models/skip.py:102. */
+ *                    = Concat + nn.Upsample: models/common.py:23-43, models/skip.py:102.  out has in0's H x W, which may be one
+ *                    row / column short of 2 x in1's (odd sizes): Concat's centre-crop (models/common.py:31-41) then drops the
+ *                    up-sampled branch's last row / column.  Any other size relation is rejected. */
 typedef struct {
     int32_t type;
     int32_t in0, in1, out;

@@ -249,7 +249,12 @@ class MeanFieldVI(nn.Module):
                 if a['pad'] or a['up'] or b['pad'] or not b['up']:
                     fail("Concat expects (skip branch, up-sampled deeper branch)")
                 ta, tb = P.tensors[a['tid']], P.tensors[b['tid']]
-                out = P.tensor(ta['C'] + tb['C'], 2 * tb['H'], 2 * tb['W'])
+                # Concat centre-crops to the smaller branch (models/common.py:31-41): in skip() that is the up-sampled branch losing its last row /
+                # column at an odd size (crop offset 0); any other size relation is outside the family
+                if not (0 <= 2 * tb['H'] - ta['H'] <= 1 and 0 <= 2 * tb['W'] - ta['W'] <= 1):
+                    raise NotImplementedError("Concat of %dx%d with the x2 up-sampling of %dx%d: only the crop of the up-sampled branch by one "
+                                              "row / column is built" % (ta['H'], ta['W'], tb['H'], tb['W']))
+                out = P.tensor(ta['C'] + tb['C'], ta['H'], ta['W'])
                 P.concat_up(a['tid'], b['tid'], out, b['up'])
                 return dict(tid=out, pad=0, up=None)
             if isinstance(m, nn.ReflectionPad2d):

@@ -282,7 +282,7 @@ constexpr int CB_ROWS = 2 * CB_TH + 2, CB_PITCH = CB_TW + 1;      // staged rows
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void concat_up_bwd_kernel(GView gc, TView a, int has_a, float* __restrict__ ga_a,
                                                             long long ga_a_sstride, double* __restrict__ bsums_a,
                                                             TView b, float* __restrict__ ga_b, long long ga_b_sstride,
-                                                            double* __restrict__ bsums_b, int tiles_x, int nearest)
+                                                            double* __restrict__ bsums_b, int tiles_x, int nearest, int pairs)
 {
     __shared__ ChanFwd s_ch;
     __shared__ ChanBwd s_cg;
@@ -322,13 +322,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             const bool ok = r < H && q < W;
             pixs[j] = ok ? r * W + q : -1;
             const int pix = ok ? pixs[j] : 0;
-            g2[j] = *reinterpret_cast<const f2a*>(gap + pix);
-            if (cat_bn) y2[j] = *reinterpret_cast<const f2a*>(ycp + pix);
-            if (dst_bn) yv2[j] = *reinterpret_cast<const f2a*>(yd + pix);
+            if (pairs) {
+                g2[j] = *reinterpret_cast<const f2a*>(gap + pix);
+                if (cat_bn) y2[j] = *reinterpret_cast<const f2a*>(ycp + pix);
+                if (dst_bn) yv2[j] = *reinterpret_cast<const f2a*>(yd + pix);
+            } else {      // odd width (Concat crop) / unaligned rows: element loads, the second element may lie beyond the row
+                const int p1 = (ok && q + 1 < W) ? pix + 1 : pix;
+                g2[j].x = gap[pix]; g2[j].y = gap[p1];
+                if (cat_bn) { y2[j].x = ycp[pix]; y2[j].y = ycp[p1]; }
+                if (dst_bn) { yv2[j].x = yd[pix]; yv2[j].y = yd[p1]; }
+                if (ok && q + 1 >= W) pixs[j] = -2 - pix;      // only the first element exists
+            }
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            if (pixs[j] < 0) continue;
+            if (pixs[j] == -1) continue;
+            const bool single = pixs[j] < -1;
+            const int pix0 = single ? -2 - pixs[j] : pixs[j];
             float d[2] = {g2[j].x, g2[j].y};
             if (cat_bn) { d[0] = apply_bwd(cg, g2[j].x, y2[j].x); d[1] = apply_bwd(cg, g2[j].y, y2[j].y); }
             if (dst_bn) {
@@ -338,17 +348,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
                     const float v = __builtin_fmaf(yy[l] - ch.mean, ch.scale, ch.beta);
                     if (dst.act && !(v > 0.f)) d[l] *= dst.slope;
                 }
+                if (single) d[1] = 0.f;
                 // float partials over the pair, folded into the thread's fp64 sums
                 sg += (double)(d[0] + d[1]);
                 sgx += (double)__builtin_fmaf(d[0], (yy[0] - ch.mean) * ch.rstd, d[1] * ((yy[1] - ch.mean) * ch.rstd));
             }
-            f2a o2; o2.x = d[0]; o2.y = d[1];
-            *reinterpret_cast<f2a*>(go + pixs[j]) = o2;
+            if (pairs) { f2a o2; o2.x = d[0]; o2.y = d[1]; *reinterpret_cast<f2a*>(go + pix0) = o2; }
+            else { go[pix0] = d[0]; if (!single) go[pix0 + 1] = d[1]; }
         }
     } else {
         // ---- stage dy of the hi-res window: local row lr <-> hi-res row 2*m0-1+lr, local col lc <-> hi-res col 2*n0-1+lc;
         //      even lc -> s_e[lr][lc/2], odd lc -> s_o[lr][lc/2].  Slot 0: lc 0; slots 1..CB_TW: lc (2s-1, 2s); slot CB_TW+1: lc 2*CB_TW+1.
-        const int gr0 = 2 * m0 - 1, gc0 = 2 * n0 - 1;
+        const int gr0 = 2 * m0 - 1;
         constexpr int SLOTS = CB_TW + 2, NS = (CB_ROWS * SLOTS + 255) / 256;
         // slot sl of a window row = the aligned pair at hi-res columns (2*n0 - 2 + 2*sl, +1): .x -> s_o[lr][sl-1], .y -> s_e[lr][sl]
         // (slot 0 only contributes its .y, the last slot only its .x); branch-free: clamped address, zeroed when outside the image
@@ -359,8 +370,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             const int gr = gr0 + lr, gq = 2 * n0 - 2 + 2 * sl;
             ok[j] = gr >= 0 && gr < H && gq >= 0 && gq < W;
             const int pix = ok[j] ? gr * W + gq : 0;
-            g2[j] = *reinterpret_cast<const f2a*>(gap + pix);
-            if (cat_bn) y2[j] = *reinterpret_cast<const f2a*>(ycp + pix);
+            if (pairs) {
+                g2[j] = *reinterpret_cast<const f2a*>(gap + pix);
+                if (cat_bn) y2[j] = *reinterpret_cast<const f2a*>(ycp + pix);
+            } else {      // odd width / unaligned rows: element loads; column gq + 1 may be the (dropped) column W
+                const bool two = ok[j] && gq + 1 < W;
+                const int p1 = two ? pix + 1 : pix;
+                g2[j].x = gap[pix]; g2[j].y = two ? gap[p1] : 0.f;
+                if (cat_bn) { y2[j].x = ycp[pix]; y2[j].y = ycp[p1]; }
+                if (ok[j] && !two) ok[j] = 2;      // second element outside the image: staged as zero
+            }
         }
         // raw destination values of this thread's outputs (LeakyReLU' and x-hat of the BN-backward sums), requested with the batch above
         const int nl = t & 63, n = n0 + nl;
@@ -377,6 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             float d0 = g2[j].x, d1 = g2[j].y;
             if (cat_bn) { d0 = apply_bwd(cg, g2[j].x, y2[j].x); d1 = apply_bwd(cg, g2[j].y, y2[j].y); }
             if (!ok[j]) { d0 = 0.f; d1 = 0.f; }
+            if (ok[j] == 2) d1 = 0.f;
             if (sl >= 1) s_o[lr][sl - 1] = d0;
             if (sl <= CB_TW) s_e[lr][sl] = d1;
         }
@@ -609,7 +629,7 @@ int launch_lrt_drho(const float* dsig2, const float* rho, long long n, float* dr
 
 int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int nearest, int n_samples, hipStream_t st)
 {
-    const int H = 2 * b.H, W = 2 * b.W;
+    const int H = a ? a->H : 2 * b.H, W = a ? a->W : 2 * b.W;          // Concat's centre-crop: the up-sampled branch loses its last row / column when the skip branch is odd-sized
     const int Ct = (a ? a->C : 0) + b.C;
     const long long HW = (long long)H * W;
     TView av = a ? *a : b;
@@ -628,13 +648,15 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
                          const TView& b, float* ga_b, long long ga_b_sstride, double* bsums_b, int nearest, int n_samples, hipStream_t st)
 {
     const int Ct = (a ? a->C : 0) + b.C;
-    if ((gc.W & 1) || ((gc.gstride | gc.ystride) & 1) || (a && ((a->sstride | ga_a_sstride) & 1))) {
-        set_error("concat_up_bwd: odd width or sample stride"); return -1; }
+    // aligned pairs (float2) when every row starts on an even element; odd widths (Concat's crop) / odd strides take element loads
+    const auto al8 = [](const void* q) { return ((uintptr_t)q & 7) == 0; };
+    const int pairs = !((gc.W & 1) || ((gc.gstride | gc.ystride) & 1) || !al8(gc.ga) || (gc.y && !al8(gc.y)) ||
+                        (a && (((a->sstride | ga_a_sstride) & 1) || !al8(a->data) || !al8(ga_a))));
     const int tiles_x = (b.W + CB_TW - 1) / CB_TW, tiles_y = (b.H + CB_TH - 1) / CB_TH;
     dim3 grid((unsigned)(tiles_x * tiles_y), Ct, n_samples);
     TView av = a ? *a : b;
     hipLaunchKernelGGL(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
-                       ga_b_sstride, bsums_b, tiles_x, nearest);
+                       ga_b_sstride, bsums_b, tiles_x, nearest, pairs);
     return (int)hipGetLastError();
 }
 

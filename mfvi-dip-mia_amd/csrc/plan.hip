@@ -135,13 +135,16 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
             int Ca = 0;
             if (d.in0 >= 0) {
                 const TensorInfo& a = p.t[d.in0]; Ca = a.d.C;
-                // Concat centre-crops to the smaller input (models/common.py:31-41); only the no-crop case is built
-                if (a.d.H != 2 * b.d.H || a.d.W != 2 * b.d.W) return fail("plan: op %d: concat inputs differ in size (%dx%d vs 2*%dx%d): centre-crop not implemented; use H,W divisible by 2^n_scales", i, a.d.H, a.d.W, b.d.H, b.d.W);
+                // Concat centre-crops to the smaller input (models/common.py:31-41).  In skip() the up-sampled branch is 2*ceil(H/2) against
+                // the skip branch's H, so the crop offset (size - target) / 2 is 0 and at most its last row / column is dropped.
+                if (2 * b.d.H < a.d.H || 2 * b.d.H - a.d.H > 1 || 2 * b.d.W < a.d.W || 2 * b.d.W - a.d.W > 1)
+                    return fail("plan: op %d: concat inputs %dx%d vs 2*%dx%d: only the crop of the up-sampled branch by one row / column is built", i, a.d.H, a.d.W, b.d.H, b.d.W);
                 if (d.in0 == p.input) return fail("plan: op %d: the net input cannot feed a concat", i);
                 p.t[d.in0].consumers.push_back(i);
             }
             if (d.in1 == p.input) return fail("plan: op %d: the net input cannot feed an upsample", i);
-            if (y.d.C != Ca + b.d.C || y.d.H != 2 * b.d.H || y.d.W != 2 * b.d.W) return fail("plan: op %d: concat output shape mismatch", i);
+            const int cH = d.in0 >= 0 ? p.t[d.in0].d.H : 2 * b.d.H, cW = d.in0 >= 0 ? p.t[d.in0].d.W : 2 * b.d.W;
+            if (y.d.C != Ca + b.d.C || y.d.H != cH || y.d.W != cW) return fail("plan: op %d: concat output shape mismatch", i);
             p.t[d.in1].consumers.push_back(i);
         } else return fail("plan: op %d: unknown type %d", i, d.type);
         // inputs must already be produced (program order = execution order)

@@ -219,11 +219,14 @@ def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(1
         deep, kk = d2, nd[i]
         if i < len(nd) - 1:
             deep, kk = scale(i + 1, d2), nu[i + 1]
-        cat = P.tensor(ns[i] + kk, h, w); P.concat_up(s, deep, cat, upsample_mode); P.set_bn(cat, act=False)
+        # Concat centre-crops the up-sampled branch to the skip branch (models/common.py:31-41): at an odd h the 2*ceil(h/2) rows lose the last
+        # one.  Without a skip branch there is no Concat and the up-sampled size stands (models/skip.py:62-66).
+        ch, cw = (h, w) if s is not None else (2 * P.tensors[deep]["H"], 2 * P.tensors[deep]["W"])
+        cat = P.tensor(ns[i] + kk, ch, cw); P.concat_up(s, deep, cat, upsample_mode); P.set_bn(cat, act=False)
         u = P.tensor(nu[i], *P.conv_out_hw(cat, fu, 1)); P.conv(cat, u, fu, 1); P.set_bn(u, act=True)
         top_i = u
         if need1x1_up:
-            top_i = P.tensor(nu[i], h, w); P.conv(u, top_i, 1, 1); P.set_bn(top_i, act=True)
+            top_i = P.tensor(nu[i], ch, cw); P.conv(u, top_i, 1, 1); P.set_bn(top_i, act=True)
         for t, p in ((d1, drop_down), (d2, drop_down), (u, drop_up)) + (((top_i, drop_up),) if need1x1_up else ()):
             if p:
                 P.set_dropout(t, p)
@@ -231,6 +234,6 @@ def skip_program(H, W, input_depth=16, n_out=2, nd=(16, 32, 64, 128, 128), nu=(1
         return top_i
 
     top = scale(0, zin)
-    out = P.tensor(n_out, H, W); P.conv(top, out, 1, 1)
+    out = P.tensor(n_out, P.tensors[top]["H"], P.tensors[top]["W"]); P.conv(top, out, 1, 1)
     del P.conv
     return P, zin, out, names

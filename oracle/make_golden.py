@@ -724,6 +724,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--lrt" in sys.argv:
         golden_lrt(); sys.exit(0)
+    if "--crop" in sys.argv:            # sides not divisible by 2^n_scales: Concat's centre-crop (models/common.py:29-41) at the deepest scale, both dims
+        golden_net("crop_den_36x44_k1", O.make_net(36, 44, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4)), seed=31, K=1, task="den",
+                   full_arrays=True)
+        sys.exit(0)
     if "--bookkeeping" in sys.argv:
         golden_bookkeeping(); sys.exit(0)
     if "--inp-dip" in sys.argv:

@@ -49,8 +49,9 @@ def test_state_dict_keys_match_reference(M, golden_dir):
     assert abs(per - float(kl)) < 1e-5 * float(kl)
 
 
-def test_reference_style_training_step(M):
-    kw = dict(H=32, W=32, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
+@pytest.mark.parametrize("H,W", [(32, 32), (36, 44)])      # 36 x 44: 9 -> 5 rows, 11 -> 6 columns at the third scale, Concat crops (models/common.py:31-41)
+def test_reference_style_training_step(M, H, W):
+    kw = dict(H=H, W=W, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4))
     onet = O.make_net(**kw)
     seed, temp, sig = 5, 5.656911698337764e-07, 1.4616642493692077e-05
     mu, rho, bnp = O.init_params(onet, seed)
@@ -60,13 +61,13 @@ def test_reference_style_training_step(M):
     prior = {'mu': 0.0, 'sigma': np.sqrt(temp) * sig}
     net = M.MeanFieldVI(net, prior=prior, replace_layers='all', device=device, reparam='', seed=seed)
     _load_flat(net, mu, rho, bnp)
-    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, 8 * 32 * 32)).reshape(1, 8, 32, 32)
-    tgt = O.noisy(O.phantom(32, 32, seed), 0.1, seed)
+    z = (0.1 * O.uniform_fill(seed, 0, 0, 0, 8 * H * W)).reshape(1, 8, H, W)
+    tgt = O.noisy(O.phantom(H, W, seed), 0.1, seed)
     net_input = torch.from_numpy(z).to(device); img = torch.from_numpy(tgt)[None, None].to(device)
     optimizer = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0)
     optimizer.zero_grad()
     out = net(net_input)
-    assert out.shape == (1, 2, 32, 32) and out.requires_grad
+    assert out.shape == (1, 2, H, W) and out.requires_grad
     nll = M.gaussian_nll(out[:, :1], out[:, 1:], img)
     kl = net.kl()
     loss = nll + temp * kl

@@ -120,6 +120,10 @@ NET_CASES = {
     "two_scale_40x72": dict(H=40, W=72, input_depth=8, n_out=1, nd=(8, 16), nu=(8, 16), ns=(4, 4)),
     "three_scale_32": dict(H=32, W=32, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4)),
     "three_scale_skip2_48x64": dict(H=48, W=64, input_depth=4, n_out=2, nd=(8, 12, 20), nu=(8, 12, 20), ns=(2, 3, 5)),
+    # sizes not divisible by 2^n_scales: Concat centre-crops the up-sampled branch (models/common.py:31-41).  36 -> 18 -> 9 -> 5 rows,
+    # 44 -> 22 -> 11 -> 6 columns; 35 x 45 is odd from the first scale on
+    "crop_three_scale_36x44": dict(H=36, W=44, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4)),
+    "crop_two_scale_35x45": dict(H=35, W=45, input_depth=4, n_out=1, nd=(8, 12), nu=(8, 12), ns=(4, 2)),
 }
 
 
@@ -224,7 +228,7 @@ def test_full_net_against_reference_golden(M, golden_dir, name, size):
     assert relerr(host(out_eval)[0], g["out_eval"]) < 1e-4
 
 
-@pytest.mark.parametrize("name,task", [("small_den_k2", 0), ("small_sr_k1", 1), ("small_ct_k1", 2)])
+@pytest.mark.parametrize("name,task", [("small_den_k2", 0), ("small_sr_k1", 1), ("small_ct_k1", 2), ("crop_den_36x44_k1", 0)])
 def test_small_golden_elbo_grad(M, golden_dir, name, task):
     """den / SR / CT losses on small nets vs the reference goldens (K-sample loop, loss averaged over K)."""
     from test_oracle_golden import NETS

@@ -122,6 +122,8 @@ NETS = {
     "full_sr256_d32_k1": (dict(H=256, W=256, input_depth=32), 1),
     "full_ct_256_k1": (dict(H=256, W=256, n_out=1), 2),
     "full_den_128_k1_bf16": (dict(H=128, W=128), 0),
+    # sides not divisible by 2^n_scales: Concat's centre-crop (models/common.py:29-41) at the deepest scale, in both dimensions
+    "crop_den_36x44_k1": (dict(H=36, W=44, input_depth=8, n_out=2, nd=(8, 16, 16), nu=(8, 16, 16), ns=(4, 4, 4)), 0),
 }
 
 
