@@ -266,7 +266,6 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
             __builtin_amdgcn_s_setprio(2);                                // younger half of the workgroup: do not starve behind the MFMA stream
             float4 pxr[CPW][NPX], pgr[4][NPG], pyr[4][NPG];
             int pxo[NPX], pgo[NPG];                                       // element offsets; input: low 2 bits = 1 left / 2 right reflected
-            __syncthreads();                                             // (S0) channel tables visible
             auto pfetch = [&](int tile) {
                 const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
 #pragma unroll
@@ -329,7 +328,8 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
                     }
                 }
             };
-            if (tile_begin < tile_end) pfetch(tile_begin);
+            if (tile_begin < tile_end) pfetch(tile_begin);               // requested before the channel tables exist: only the staging transform needs them
+            __syncthreads();                                             // (S0) channel tables visible
             for (int tile = tile_begin; tile < tile_end; ++tile) {
                 if (tile > tile_begin) __syncthreads();                  // (B1) consumers are done with the previous tile
                 pstage();

@@ -168,16 +168,20 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     ChanFwd* __restrict__ s_ch = reinterpret_cast<ChanFwd*>(s_w + (WS ? KK * REDP * CTP : 2 * WCHUNK));
     ChanBwd* __restrict__ s_chb = reinterpret_cast<ChanBwd*>(s_ch + ((g.Cin + 3) & ~3));
 
-    if (MODE == 0) {
-        for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c);
-        if (tid < CT) {
-            const int co = m0 + tid;
-            const float b = (co < g.Cout && g.b_off >= 0) ? wk[g.b_off + co] : 0.f;
-            s_bias[tid] = b;
+    // built by the consumer waves, which have nothing else to do before the first stage is published; the producers go straight to their
+    // first global loads (the tables' statistics loads + fp64 arithmetic were ~1.5 us in front of every block's first request)
+    if (!producer) {
+        if (MODE == 0) {
+            for (int c = tid; c < g.Cin; c += 256) s_ch[c] = chan_fwd(A.xin, k, c);
+            if (tid < CT) {
+                const int co = m0 + tid;
+                const float b = (co < g.Cout && g.b_off >= 0) ? wk[g.b_off + co] : 0.f;
+                s_bias[tid] = b;
+            }
+        } else {
+            for (int c = tid; c < g.Cout; c += 256) s_chb[c] = chan_bwd(A.gin, k, c);
+            if constexpr (KS == 1 || FF) { if (A.fga) for (int c = tid; c < g.Cin; c += 256) s_ch[c] = chan_fwd(A.xin, k, c); }
         }
-    } else {
-        for (int c = tid; c < g.Cout; c += 512) s_chb[c] = chan_bwd(A.gin, k, c);
-        if constexpr (KS == 1 || FF) { if (A.fga) for (int c = tid; c < g.Cin; c += 512) s_ch[c] = chan_fwd(A.xin, k, c); }
     }
     const bool fuse = MODE == 1 && (KS == 1 || FF) && A.fga != nullptr;
     const bool fuse_sums = fuse && A.fbsums != nullptr;

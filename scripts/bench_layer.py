@@ -21,6 +21,8 @@ else:
 plan = P.compile(zin, out, K)
 mu = 0.1 * torch.randn(P.n_vi, device="cuda"); rho = -3 + 0.1 * torch.randn(P.n_vi, device="cuda")
 bn = torch.ones(max(P.n_bn, 1), device="cuda"); z = torch.randn(cin * H * W, device="cuda")
+if int(os.environ.get("AUTOTUNE", "1")) and not os.environ.get("MFVI_TUNE"):
+    plan.autotune(mu, rho, bn, z, K)
 o = plan.forward(mu, rho, bn, z, 1, 0, 0, K)
 dout = torch.randn_like(o); dmu = torch.zeros_like(mu); drho = torch.zeros_like(rho); dbn = torch.zeros_like(bn)
 dz = torch.empty(K * cin * H * W, device="cuda")
@@ -38,6 +40,8 @@ for o_, p_, ms in recs:
 Ho, Wo = P.tensors[P.ops[op]["out"]]["H"], P.tensors[P.ops[op]["out"]]["W"]
 flops = 2.0 * K * cout * cin * k * k * Ho * Wo
 names = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold"}
+tn = [M._lib.lib().mfvi_plan_get_tune(plan.handle, op, w) for w in range(3)]
+print("tunes fwd mf=%d th=%d T=%d | bwd-data mf=%d th=%d T=%d | bww nb=%d w=%d tgt=%d" % (tn[0] & 255, (tn[0] >> 8) & 255, tn[0] >> 16, tn[1] & 255, (tn[1] >> 8) & 255, tn[1] >> 16, tn[2] & 255, (tn[2] >> 8) & 255, tn[2] >> 16))
 for p_ in (0, 2, 1, 3):
     if (op, p_) in by:
         v = sorted(by[(op, p_)]); med = v[len(v) // 2]
