@@ -141,7 +141,9 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                        void* workspace, float* out_scratch, float* grad_scratch, void* stream);
 /* Tiling in use for conv op `op`: which 0 forward, 1 backward-data (mf | th << 8 | T << 16; th bit 128 = tiles of whole rows for
  * narrow maps, th bit 64 (backward-data of layers with 16n + 4 input channels) = the last 4 channels on the 4x4x1 matrix instruction
- * instead of a padded 16-channel fragment), 2 backward-weight (input tiles | waves << 8 | block target/256 << 16); 0 = built-in heuristic. */
+ * instead of a padded 16-channel fragment), 2 backward-weight (input tiles | waves << 8 | block target/256 << 16; waves: 4, 8, 9 = 8 waves
+ * producer/consumer specialised, 10 = the fragment-split variant with input tiles = 2: one block per 32-36 input channels, the accumulator
+ * fragments dealt to the consumer waves); 0 = built-in heuristic. */
 int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which);
 int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
 

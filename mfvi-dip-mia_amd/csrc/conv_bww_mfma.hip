@@ -405,6 +405,255 @@ __global__ __launch_bounds__(NT) void conv_bww_mfma_kernel(TView in, GView gy, C
     if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = (s_db[t] + s_db[16 + t]) + (s_db[32 + t] + s_db[48 + t]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fragment-split variant for the 3x3 stride-1 layers on full-width tiles (w field 10).  A block owns 16 output channels and a group
+// of up to 36 input channels (two 16-channel tiles + the 4-channel remainder of the 16n + 4 concat layers), so dy — the operand whose
+// BN-backward staging the other variants repeat once per 16 input channels — is staged ONCE per 32-36 of them.  What makes that fit
+// the register file: the (input tile, tap) accumulator fragments (up to 18 + 9 of the 4x4x1 kind) are dealt to the 4 consumer waves
+// (wave w owns fragments w, w + 4, ...), each wave sweeps ALL k-steps of the tile for its own <= 7 fragments, and there is no
+// cross-wave reduction at the end.  Same tile, staging and slab layout as the specialised variant above.
+struct SCfg {
+    static constexpr int TW = 32, TH = 8, KK = 9, CIB = 36;
+    static constexpr int IN_TH = TH + 2, IN_TW = TW + 2, HALO4 = 4, XOFF = 3;
+    static constexpr int WV = (XOFF + IN_TW + 3) / 4 * 4;                 // 40
+    static constexpr int GPLANE = pitch2(TH * TW), XPLANE = pitch2(IN_TH * WV);
+    static constexpr int STAGE = 16 * GPLANE + CIB * XPLANE;
+    static constexpr int ROW = CIB * KK, ROWP = ROW + 2;
+    static constexpr int EPI = 16 * ROWP + 16;
+    static constexpr int LDS_FLOATS = STAGE > EPI ? STAGE : EPI;
+};
+
+__global__ __launch_bounds__(512, 4) void conv_bww_split_kernel(TView in, GView gy, ConvGeom g, float* __restrict__ part, long long part_stride,
+                                                                int tiles_x, int n_tiles, int tiles_per_block, int ci_groups, int nx, int ny, int nz)
+{
+    using Cfg = SCfg;
+    constexpr int TW = Cfg::TW, TH = Cfg::TH, KK = Cfg::KK, P = 1, IN_TH = Cfg::IN_TH, CIB = Cfg::CIB;
+    constexpr int GPLANE = Cfg::GPLANE, XPLANE = Cfg::XPLANE, WV = Cfg::WV, XOFF = Cfg::XOFF, ROWP = Cfg::ROWP;
+    extern __shared__ __align__(16) float lds[];
+    __shared__ ChanFwd s_chx[CIB];
+    __shared__ ChanBwd s_chg[16];
+    float* s_g = lds;                    // [16][GPLANE]
+    float* s_x = lds + 16 * GPLANE;      // [CIB][XPLANE]
+
+    const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform for the compiler too: the per-wave dispatch below must be scalar branches
+    const bool producer = wv >= 4;
+    int bx, by, k;
+    xcd_decode(blockIdx.x, nx, ny, nz, bx, by, k);
+    const int co0 = (by / ci_groups) * 16, ci0 = (by % ci_groups) * 32;
+    const int Cin = g.Cin, Cout = g.Cout, H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
+    const bool do_bias = (ci0 == 0) && (g.b_off >= 0);
+    const int cot = min(16, Cout - co0), cit = min(CIB, Cin - ci0);      // launcher: cit in {16, 20, 32, 36}
+    const int nfull = cit >> 4; const bool x4 = (cit & 15) != 0;
+
+    if (t < CIB) s_chx[t] = chan_fwd(in, k, min(ci0 + t, Cin - 1));
+    if (t >= 64 && t < 80) s_chg[t - 64] = chan_bwd(gy, k, min(co0 + t - 64, Cout - 1));
+
+    const float* __restrict__ xin = in.data + (long long)k * in.sstride;
+    const float* __restrict__ gap = gy.ga + (long long)k * gy.gstride;
+    const float* __restrict__ yp = gy.y ? gy.y + (long long)k * gy.ystride : nullptr;
+    const int HW = H * W, HWo = Ho * Wo;
+    const int tile_begin = bx * tiles_per_block, tile_end = min(n_tiles, tile_begin + tiles_per_block);
+
+    constexpr int MAXF = 7;
+    float* s_ep = lds;                      // [16][ROWP]   (epilogue, over the tile)
+    float* s_db = lds + 16 * ROWP;          // [16]
+
+    if (producer) {
+        // producer wave pw stages input channels [9 pw, 9 pw + 9) as the specialised variant does (72 registers of prefetched tile); the
+        // gradient tile is staged by the CONSUMER waves, which have the registers to spare and idle between (B1) and (B2) anyway
+        constexpr int CPW = CIB / 4;
+        constexpr int NV4 = WV / 4, NXI = IN_TH * NV4, NPX = (NXI + 63) / 64;
+        const int pw = wv - 4;
+        __builtin_amdgcn_s_setprio(2);
+        float4 pxr[CPW][NPX];
+        int pxo[NPX];
+        auto pfetch = [&](int tile) {
+            const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+            const int ax0 = ox0 - Cfg::HALO4;
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                const int q = min(lane + 64 * j, NXI - 1), iy = q / NV4, v = q - iy * NV4;
+                int gyy = reflect_idx(oy0 + iy - P, H); gyy = min(max(gyy, 0), H - 1);
+                int gx = ax0 + 4 * v, flag = 0;
+                if (gx < 0) { flag = 1; gx = 0; } else if (gx >= W) { flag = gx == W ? 2 : 0; gx = W - 4; }
+                pxo[j] = (gyy * W + gx) | flag;
+#pragma unroll
+                for (int i = 0; i < CPW; ++i)
+                    pxr[i][j] = *reinterpret_cast<const float4*>(xin + (long long)(ci0 + min(pw * CPW + i, cit - 1)) * HW + (pxo[j] & ~3));
+            }
+        };
+        auto pstage = [&]() {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                const int c = pw * CPW + i;
+                if (c >= cit) break;
+                const ChanFwd cx = s_chx[c];
+#pragma unroll
+                for (int j = 0; j < NPX; ++j) {
+                    const int q = lane + 64 * j, flag = pxo[j] & 3;
+                    float e[4] = {pxr[i][j].x, pxr[i][j].y, pxr[i][j].z, pxr[i][j].w};
+                    apply_fwd4(cx, e, in.act, in.slope);
+                    if (flag == 1) e[3] = e[1];                       // column -1 <- x[1]
+                    else if (flag == 2) e[0] = e[2];                  // column W  <- x[W-2]
+                    if (64 * (j + 1) <= NXI || q < NXI) lds_store4(s_x + c * XPLANE + 4 * q, e[0], e[1], e[2], e[3]);
+                }
+            }
+        };
+        if (tile_begin < tile_end) pfetch(tile_begin);
+        __syncthreads();                                             // (S0) channel tables visible
+        for (int tile = tile_begin; tile < tile_end; ++tile) {
+            if (tile > tile_begin) __syncthreads();                  // (B1) consumers are done with the previous tile
+            pstage();
+            __syncthreads();                                         // (B2) tile published
+            if (tile + 1 < tile_end) pfetch(tile + 1);
+        }
+        __syncthreads();                                             // (E) consumers are done with the last tile
+    } else {
+        // (the accumulators live in this branch only: the producers need their registers for the prefetched tile)
+        f32x4 acc[MAXF], accb;
+        // consumer wave wv prefetches / stages gradient channels [4 wv, 4 wv + 4): one aligned float4 of dy and of y per lane and channel
+        constexpr int PIX = TH * TW, NGI = PIX / 4;
+        static_assert(NGI == 64, "one float4 per lane");
+        float4 pgr[4], pyr[4];
+        int pgo = -1;
+        auto cfetch = [&](int tile) {
+            const int ox0 = (tile % tiles_x) * TW, oy0 = (tile / tiles_x) * TH;
+            const int yy = oy0 + lane / (TW / 4), xx = ox0 + (lane % (TW / 4)) * 4;
+            pgo = (yy < Ho && xx < Wo) ? yy * Wo + xx : -1;
+            const int gsafe = max(pgo, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = (co0 + min(wv * 4 + i, cot - 1)) * HWo + gsafe;
+                pgr[i] = *reinterpret_cast<const float4*>(gap + off);
+                pyr[i] = yp ? *reinterpret_cast<const float4*>(yp + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto cstage = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = wv * 4 + i;
+                const ChanBwd cgk = s_chg[c];
+                float e[4] = {pgr[i].x, pgr[i].y, pgr[i].z, pgr[i].w};
+                if (yp) {
+                    const float yy[4] = {pyr[i].x, pyr[i].y, pyr[i].z, pyr[i].w};
+                    apply_bwd4(cgk, e, yy);
+                }
+                if (pgo < 0 || c >= cot) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+                lds_store4(s_g + c * GPLANE + 4 * lane, e[0], e[1], e[2], e[3]);
+            }
+        };
+        // ---- consumer wave W of 4, NF full input tiles, X4 = remainder group present: fragments f = W + 4j < 9 NF + 9 X4;
+        //      f < 9 NF: 16x16x4 on input tile f / 9, tap f % 9;  else the 4x4x1 instruction on channels 16 NF .. 16 NF + 3, tap f - 9 NF.
+        //      Software pipeline as in the specialised variant: the LDS reads of k-step i + 1 are woven between the MFMAs of k-step i.
+        auto sweep = [&](auto w_c, auto nf_c, auto x4_c, auto bias_c) {
+            constexpr int WI = decltype(w_c)::value, NF = decltype(nf_c)::value;
+            constexpr bool X4 = decltype(x4_c)::value, BIAS = decltype(bias_c)::value;
+            constexpr int NFRAG = 9 * NF + (X4 ? 9 : 0);
+            constexpr int NJ = (NFRAG - WI + 3) / 4;                     // fragments of this wave
+            static_assert(NJ >= 1 && NJ <= MAXF, "fragment count");
+            const float* xb16 = s_x + l15 * XPLANE + l4 + XOFF;                          // full fragments: plane = channel l15 of the tile
+            const float* xb4 = s_x + (NF * 16 + (l15 & 3)) * XPLANE + l4 + XOFF;         // 4x4x1 fragments: plane = remainder channel lane & 3
+            const float* ga = s_g + l15 * GPLANE + l4;
+            auto boff = [](int j) constexpr { const int f = WI + 4 * j; const bool full = f < 9 * NF; const int tp = full ? f % 9 : f - 9 * NF;
+                                               return (full ? (f / 9) * 16 * XPLANE : 0) + (tp / 3) * WV + (tp % 3); };
+            auto isfull = [](int j) constexpr { return WI + 4 * j < 9 * NF; };
+            float a[2], b[2][NJ];
+            // (first request, table barrier and accumulator reset sit INSIDE the per-wave variant: placed in front of the dispatch, the
+            //  loop-invariant addresses the compiler hoists out of all 16 variants were live together with them: 146 registers)
+            if (tile_begin < tile_end) cfetch(tile_begin);
+            __syncthreads();                                             // (S0)
+            accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < MAXF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // reads of the k-step at (gp, xp16 / xp4) into (an, bn), woven into the MFMAs of (aa, bb)
+            auto step = [&](float aa, const float (&bb)[NJ], const float* gp, const float* xp16, const float* xp4, float& an, float (&bn)[NJ]) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bn[j] = isfull(j) ? xp16[boff(j)] : xp4[boff(j)];
+                    if (j == 0) an = gp[0];
+                    if (isfull(j)) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb[j], acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(aa, bb[j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, 1.0f, accb, 0, 0, 0);
+            };
+            for (int tile = tile_begin; tile < tile_end; ++tile) {
+                if (tile > tile_begin) __syncthreads();                  // (B1)
+                cstage();
+                __syncthreads();                                         // (B2)
+                const int vr = min(TH, Ho - (tile / tiles_x) * TH);
+                const float* gp = ga; const float* xp16 = xb16; const float* xp4 = xb4;
+                a[0] = gp[0];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[0][j] = isfull(j) ? xp16[boff(j)] : xp4[boff(j)];
+                auto row = [&]() {
+                    // 8 k-steps of the row, every operand at a compile-time offset from the three row pointers; the last one requests the first
+                    // k-step of the next row (below the tile's last row that is a row of the next plane, or zeros past the allocation: unused)
+#pragma unroll
+                    for (int c = 0; c < 8; c += 2) {
+                        step(a[0], b[0], gp + 4 * (c + 1), xp16 + 4 * (c + 1), xp4 + 4 * (c + 1), a[1], b[1]);
+                        if (c + 2 < 8) step(a[1], b[1], gp + 4 * (c + 2), xp16 + 4 * (c + 2), xp4 + 4 * (c + 2), a[0], b[0]);
+                        else step(a[1], b[1], gp + TW, xp16 + WV, xp4 + WV, a[0], b[0]);
+                    }
+                    gp += TW; xp16 += WV; xp4 += WV;
+                };
+                for (int r = 0; r + 1 < vr; ++r) row();
+                // the next tile's gradient is requested before the LAST row only: its 32 registers are then live for 1/8 of the sweep instead
+                // of all of it (held across the whole sweep they did not fit beside the accumulators: 57 spilled registers)
+                if (tile + 1 < tile_end) cfetch(tile + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                row();
+            }
+        };
+        constexpr std::true_type yes{}; constexpr std::false_type no{};
+        constexpr std::integral_constant<int, 0> w0{}; constexpr std::integral_constant<int, 1> w1{}; constexpr std::integral_constant<int, 2> w2{};
+        constexpr std::integral_constant<int, 3> w3{}; constexpr std::integral_constant<int, 1> n1{}; constexpr std::integral_constant<int, 2> n2{};
+        // the bias fragment rides with wave 3 (the lightest fragment list)
+        auto by_wave = [&](auto nf_c, auto x4_c) {
+            if (wv == 0) sweep(w0, nf_c, x4_c, no);
+            else if (wv == 1) sweep(w1, nf_c, x4_c, no);
+            else if (wv == 2) sweep(w2, nf_c, x4_c, no);
+            else if (do_bias) sweep(w3, nf_c, x4_c, yes);
+            else sweep(w3, nf_c, x4_c, no);
+        };
+        if (nfull == 2) { if (x4) by_wave(n2, yes); else by_wave(n2, no); }
+        else { if (x4) by_wave(n1, yes); else by_wave(n1, no); }
+        // ---- every fragment is complete in its wave: transpose through LDS into slab rows (co, ci * 9 + tap), then contiguous stores
+        __syncthreads();                                             // (E)
+        const int nfrag = 9 * nfull + (x4 ? 9 : 0);
+#pragma unroll
+        for (int j = 0; j < MAXF; ++j) {
+            const int f = wv + 4 * j;
+            if (f >= nfrag) break;
+            if (f < 9 * nfull) {
+                const int gi = f / 9, tp = f - gi * 9;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_ep[(l4 * 4 + r) * ROWP + (gi * 16 + l15) * KK + tp] = acc[j][r];
+            } else {
+                const int tp = f - 9 * nfull;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[j][r]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                    if (lane < 16) s_ep[(4 * (lane >> 2) + r) * ROWP + (nfull * 16 + (lane & 3)) * KK + tp] = v;
+                }
+            }
+        }
+        if (do_bias && wv == 3 && l15 == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_db[l4 * 4 + r] = accb[r];
+    }
+    __syncthreads();
+    const int len = cit * KK;
+    float* __restrict__ o = part + ((long long)bx * nz + k) * part_stride;
+    for (int idx = t; idx < 16 * len; idx += 512) {
+        const int r = idx / len, rel = idx - r * len, co = co0 + r;
+        if (co < Cout) o[((long long)co * Cin + ci0) * KK + rel] = s_ep[r * ROWP + rel];
+    }
+    if (do_bias && t < cot) o[(long long)Cout * Cin * KK + co0 + t] = s_db[t];
+}
+
 int env_tune_w()
 {
     static const int t = [] { int nb = 0, w = 0, tb = 0; const char* e = getenv("MFVI_TUNE_W"); if (e) sscanf(e, "%d,%d,%d", &nb, &w, &tb); return nb > 0 ? (nb | w << 8 | tb << 16) : 0; }();
@@ -414,7 +663,7 @@ int env_tune_w()
 }  // namespace
 
 // Tiling (ConvGeom::tune[2], MFVI_TUNE_W=nb,w,target/256): nb | w << 8 | (target blocks / 256) << 16 with w = 4 (4 waves),
-// 8 (8 waves) or 9 (8 waves, producer/consumer specialised); 0 = heuristic.
+// 8 (8 waves), 9 (8 waves, producer/consumer specialised) or 10 (fragment-split variant, nb = 2: 3x3 stride 1, full-width tiles); 0 = heuristic.
 int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int n_samples,
                                 hipStream_t st)
 {
@@ -432,6 +681,29 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
     if (!forced && !vec_ok) cfg = (cfg & ~0xff00) | (4 << 8);      // heuristic falls back to the 4-wave variant
     const int nb = cfg & 255, wfield = (cfg >> 8) & 255, target = ((cfg >> 16) & 255) * 256;
     const bool spec = wfield == 9;
+    if (wfield == 10) {
+        // fragment-split variant: 3x3 stride 1, full-width tiles, aligned float4 staging, input-channel groups of 32 with a 4-channel remainder
+        // riding in the last one (Cin = 16n or 16n + 4)
+        if (g.ks != 3 || g.stride != 1 || !vec_ok || (g.Wo & 31) || nb != 2 || target < 256) return -3;
+        const int rem = g.Cin & 15;
+        if ((rem != 0 && rem != 4) || g.Cin < 16) return -3;
+        const int ci_groups = (g.Cin % 32 == 4 || g.Cin % 32 == 0) ? g.Cin / 32 : g.Cin / 32 + 1;       // 36 -> 1, 68 -> 2, 132 -> 4, 48 -> 2 (32 + 16), 52 -> 2 (32 + 20)
+        constexpr size_t lds_bytes = sizeof(float) * SCfg::LDS_FLOATS;
+        const int tiles_x = g.Wo / SCfg::TW, tiles_y = (g.Ho + SCfg::TH - 1) / SCfg::TH, n_tiles = tiles_x * tiles_y;
+        const int co_tiles = (g.Cout + 15) / 16;
+        const long long pairs = (long long)co_tiles * ci_groups * n_samples;
+        int strips = (int)((target + pairs - 1) / pairs);
+        strips = strips < 1 ? 1 : (strips > n_tiles ? n_tiles : strips);
+        if (strips > part.max_strips) strips = part.max_strips;
+        const int tpb = (n_tiles + strips - 1) / strips;
+        strips = (n_tiles + tpb - 1) / tpb;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bww_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL(conv_bww_split_kernel, dim3(strips * co_tiles * ci_groups * n_samples), dim3(512), lds_bytes, st, in, gy, g, part.base,
+                           part.stride, tiles_x, n_tiles, tpb, ci_groups, strips, co_tiles * ci_groups, n_samples);
+        if (strips_used) *strips_used = strips;
+        return (int)hipGetLastError();
+    }
     const int nt = spec ? 512 : wfield * 64;
 #define LAUNCH(KS_, S_, NB_, NT_, SP_)                                                                                            \
     {                                                                                                                          \

@@ -872,7 +872,10 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                 // backward-data of the 4 + 16n-channel concat layers: the last 4 output channels on the 4x4x1 matrix instruction (th bit 64)
                 if (which == 1 && (o.g.Cin & 15) == 4) for (int mf : {1, 2, 4}) for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | (8 | 64) << 8 | T << 16);
             }
-            else { for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16); }
+            else {
+                for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16);
+                for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(2 | 10 << 8 | tb << 16);      // fragment-split variant (3x3 stride 1, full-width tiles)
+            }
             int best = 0; float best_ms = 1e30f;
             for (int cand : cands) {
                 o.g.tune[which] = cand;

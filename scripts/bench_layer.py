@@ -21,8 +21,14 @@ else:
 plan = P.compile(zin, out, K)
 mu = 0.1 * torch.randn(P.n_vi, device="cuda"); rho = -3 + 0.1 * torch.randn(P.n_vi, device="cuda")
 bn = torch.ones(max(P.n_bn, 1), device="cuda"); z = torch.randn(cin * H * W, device="cuda")
-if int(os.environ.get("AUTOTUNE", "1")) and not os.environ.get("MFVI_TUNE"):
+if int(os.environ.get("AUTOTUNE", "1")):
     plan.autotune(mu, rho, bn, z, K)
+if os.environ.get("MFVI_TUNE") or os.environ.get("MFVI_TUNE_W"):      # forced tilings (launcher env) apply where the plan holds none
+    for w in range(3):
+        if (w < 2 and os.environ.get("MFVI_TUNE")) or (w == 2 and os.environ.get("MFVI_TUNE_W")):
+            M._lib.check(M._lib.lib().mfvi_plan_set_tune(plan.handle, op, w, 0))
+if int(os.environ.get("ALONE", "1")):
+    plan.side_stream(False)      # every kernel alone on the stream
 o = plan.forward(mu, rho, bn, z, 1, 0, 0, K)
 dout = torch.randn_like(o); dmu = torch.zeros_like(mu); drho = torch.zeros_like(rho); dbn = torch.zeros_like(bn)
 dz = torch.empty(K * cin * H * W, device="cuda")

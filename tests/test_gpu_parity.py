@@ -369,7 +369,7 @@ def _run_plan(plan, P, seed, n, z, dout):
     return host(o), host(dmu), host(drho), host(dz)
 
 
-@pytest.mark.parametrize("shape", [(36, 16, 64, 64), (68, 32, 32, 32), (132, 64, 16, 16), (36, 16, 40, 80)])
+@pytest.mark.parametrize("shape", [(36, 16, 64, 64), (68, 32, 32, 32), (132, 64, 16, 16), (36, 16, 40, 80), (36, 32, 20, 64)])
 def test_tilings_do_not_change_results(M, shape):
     """Every tiling the autotuner may pick (rectangular / FLAT tiles, fragments, tiles per block, backward-weight variants)
     computes the same numbers: forward bit-identical, gradients to summation-order rounding."""
@@ -382,7 +382,7 @@ def test_tilings_do_not_change_results(M, shape):
     ref = _run_plan(plan, P, seed, n, z, dout)
     enc = lambda a, b, c: a | b << 8 | c << 16
     fwd_bwd = [(1, 8, 1), (1, 16, 1), (2, 8, 2), (3, 8, 1), (1, 8 | 128, 1), (1, 16 | 128, 1), (2, 8 | 128, 2), (1, 4 | 128, 1), (2, 2 | 128, 1), (4, 4 | 128, 1)]
-    bww = [(1, 4, 1), (1, 8, 2), (2, 9, 1), (3, 9, 1), (3, 4, 2)]
+    bww = [(1, 4, 1), (1, 8, 2), (2, 9, 1), (3, 9, 1), (3, 4, 2), (2, 10, 1), (2, 10, 4)]      # w = 10: fragment-split variant (full-width tiles)
     # backward-data with the layer's last 4 input channels on the 4x4x1 matrix instruction (tile-height bit 64): 36 = 2*16+4, 68 = 4*16+4 ...
     rem = [(mf, 8 | 64, T) for mf, T in ((1, 1), (2, 2), (4, 1)) if (cin - 4) % (16 * mf) == 0]
     assert len(rem) >= 2
