@@ -50,6 +50,7 @@ struct mfvi_plan {
     int input = -1, output = -1, max_samples = 0;
     long long n_vi = 0, n_bn = 0;
     long long stats_doubles = 0;               // per block (fwd stats | bsums), for max_samples
+    const void* bsums_clean_ws = nullptr;      // workspace whose BN-backward sums the last forward zeroed (one memset for both blocks) with no backward since
     long long float_base = 0;                  // byte offset of the float arena
     long long total_bytes = 0;
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
@@ -483,9 +484,10 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
     if (bf16 && (((uintptr_t)mu_v | (uintptr_t)rho_v) & 7)) { set_error("forward: bf16 mu / rho must be 8-byte aligned"); return -1; }
     const float* mu = nullptr; const float* rho = nullptr;
     { const int rc = generic_params(plan, c, mu_v, rho_v, &mu, &rho, st); if (rc) { set_error("forward: bf16 expansion failed: %s", hipGetErrorString((hipError_t)rc)); return rc; } }
-    if (plan->stats_doubles) {
-        hipError_t e = hipMemsetAsync(c.fstats(), 0, sizeof(double) * plan->stats_doubles, st);
+    if (plan->stats_doubles) {      // forward statistics and (adjacent) the BN-backward sums of the backward pass that follows: one launch
+        hipError_t e = hipMemsetAsync(c.fstats(), 0, sizeof(double) * 2 * plan->stats_doubles, st);
         if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+        plan->bsums_clean_ws = workspace;
     }
     const RngKey key = base_key(seed, step, k0);
     if (plan->bn_eval && plan->n_entries) {   // nn.BatchNorm2d in eval mode: the running statistics stand in for every sample's batch sums
@@ -560,10 +562,11 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     if (bf16 && (((uintptr_t)mu_v | (uintptr_t)rho_v) & 7)) { set_error("backward: bf16 mu / rho must be 8-byte aligned"); return -1; }
     const float* mu = nullptr; const float* rho = nullptr;
     { const int rc = generic_params(plan, c, mu_v, rho_v, &mu, &rho, st); if (rc) { set_error("backward: bf16 expansion failed: %s", hipGetErrorString((hipError_t)rc)); return rc; } }
-    if (plan->stats_doubles) {
+    if (plan->stats_doubles && plan->bsums_clean_ws != workspace) {      // a second backward after one forward (gradients accumulate): the sums start from zero again
         hipError_t e = hipMemsetAsync(c.bsums(), 0, sizeof(double) * plan->stats_doubles, st);
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
+    plan->bsums_clean_ws = nullptr;
     const RngKey key = base_key(seed, step, k0);
     if (plan->n_lrt && sample_weights) {
         if (!rho) { set_error("backward: local-reparameterisation layers take float32 parameters"); return -1; }
@@ -904,6 +907,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
         }
     }
 done:
+    plan->bsums_clean_ws = nullptr;      // the timed launches accumulated into the BN-backward sums
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     if (rc) for (auto& o : plan->ops) { o.g.tune[0] = 0; o.g.tune[1] = 0; o.g.tune[2] = 0; }
     return rc;

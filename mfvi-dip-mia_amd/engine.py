@@ -49,7 +49,10 @@ class ElboEngine:
         self.n_vi, self.n_bn = P.n_vi, P.n_bn
         self.n_params = 2 * P.n_vi + P.n_bn
         dev = "cuda"
-        self.grads = torch.zeros(self.n_params + 8, dtype=torch.float32, device=dev)     # [+8]: scalars riding the all-reduce
+        # gradients (+8 scalars riding the all-reduce) and the float64 loss accumulators in ONE allocation: one fill launch clears both per iteration
+        n_g = (self.n_params + 8 + 1) // 2 * 2                                            # the accumulators start 8-byte aligned
+        self._gbuf = torch.zeros(4 * n_g + 32, dtype=torch.uint8, device=dev)
+        self.grads = self._gbuf[:4 * (self.n_params + 8)].view(torch.float32)
         self.m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         if param_dtype == "bf16":
@@ -69,7 +72,7 @@ class ElboEngine:
         self.z = torch.empty_like(self.z0)
         self.out = torch.empty((self.chunk, n_out, H, W), dtype=torch.float32, device=dev)
         self.dout = torch.empty_like(self.out)
-        self.acc = torch.zeros(4, dtype=torch.float64, device=dev)        # [0] nll sum, [1] kl
+        self.acc = self._gbuf[4 * n_g:].view(torch.float64)                # [0] nll sum, [1] kl
         self.upd_scratch = torch.zeros(L.lib().mfvi_elbo_update_scratch_bytes(), dtype=torch.uint8, device=dev)
         self.t_applied = torch.zeros(1, dtype=torch.int32, device=dev)    # CT: optimizer steps actually taken (the NaN guard skips some)
         self.sr_factor = sr_factor
@@ -146,7 +149,7 @@ class ElboEngine:
         """Everything of one iteration except the optimizer update; returns nothing (grads, acc hold the result)."""
         lib, sp = L.lib(), L.stream_ptr()
         step = self.t if step is None else step
-        self.grads.zero_(); self.acc.zero_()
+        self._gbuf.zero_()                     # grads and acc
         zsrc = self.z0
         if perturb:
             L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
