@@ -1017,6 +1017,7 @@ __global__ __launch_bounds__(512, (BIGC ? (MF * TH <= 32 ? 2 : 1) : (MF * TH <= 
     }
 }
 
+#ifndef MFVI_KERNEL_ONLY      // scripts/dev/regs_conv_mfma.sh: explicit instantiations of a few kernels for a quick register / spill report
 // MFVI_PHASE=0: stride-2 backward-data on rectangular tiles runs the zero-stuffed formulation (A/B and parity cross-checks)
 bool phase_on()
 {
@@ -1166,6 +1167,10 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
 #undef GO_
 }
 
+#else
+}  // namespace
+#endif
+#ifndef MFVI_KERNEL_ONLY
 }  // namespace
 
 // Returns -2 when the shape is not served by the MFMA path (caller falls back to the generic kernels).
@@ -1205,3 +1210,4 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
     if (g.ks == 5) return launch_variant<5, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);
     return -2;
 }
+#endif

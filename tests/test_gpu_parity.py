@@ -396,6 +396,26 @@ def test_tilings_do_not_change_results(M, shape):
                 assert relerr(a, b) < 2e-5, (name, which, cand)
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 16, 32), (20, 16, 24, 32), (32, 32, 16, 64), (48, 16, 16, 32), (52, 32, 12, 64), (96, 16, 8, 32), (100, 16, 8, 32)])
+def test_split_backward_weight_channel_groups(M, shape):
+    """Fragment-split backward-weight variant (w = 10) over every input-channel grouping it serves: one or two 16-channel tiles per block,
+    with and without the 4-channel remainder, several groups (100 = 32 + 32 + 36), partial last row tile (H = 12), bias on group 0 only."""
+    cin, cout, H, W = shape
+    n, seed = 2, 91
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 2, 1 | 4 << 8 | 1 << 16))       # plain 4-wave variant, one input tile per block
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    for tgt in (1, 3):
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 2, 2 | 10 << 8 | tgt << 16))
+        got = _run_plan(plan, P, seed, n, z, dout)
+        assert np.array_equal(got[0], ref[0])
+        for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+            assert relerr(a, b) < 2e-5, (name, tgt)
+
+
 @pytest.mark.parametrize("shape", [(132, 128, 8, 8), (128, 128, 16, 16), (68, 64, 8, 16)])
 def test_small_map_tilings_do_not_change_results(M, shape):
     """The 8x8 / 16x16 maps at the bottom of the hour-glass: FLAT tiles of 2 / 4 / 8 rows-worth of pixels with 32-channel stages in both
