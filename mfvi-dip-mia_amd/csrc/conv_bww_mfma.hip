@@ -418,7 +418,9 @@ struct SCfg {
     static constexpr int IN_TH = TH + 2, IN_TW = TW + 2, HALO4 = 4, XOFF = 3;
     static constexpr int WV = (XOFF + IN_TW + 3) / 4 * 4;                 // 40
     static constexpr int GPLANE = pitch2(TH * TW), XPLANE = pitch2(IN_TH * WV);
-    static constexpr int STAGE = 16 * GPLANE + CIB * XPLANE;
+    // + 64: the software pipeline requests the first k-step of the row BELOW the tile's last one (values unused); for the last plane that
+    // row starts up to 22 floats past the planes — kept inside the block's own allocation
+    static constexpr int STAGE = 16 * GPLANE + CIB * XPLANE + 64;
     static constexpr int ROW = CIB * KK, ROWP = ROW + 2;
     static constexpr int EPI = 16 * ROWP + 16;
     static constexpr int LDS_FLOATS = STAGE > EPI ? STAGE : EPI;
