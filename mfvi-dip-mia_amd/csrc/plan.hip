@@ -71,6 +71,7 @@ struct mfvi_plan {
     // stream of the plan, forked per layer behind the event that marks "dy of this layer is final" and joined before grad_finalize,
     // so they fill the CUs the latency-bound backward-data / fold kernels of the small maps leave idle.
     hipStream_t side = nullptr; std::vector<hipEvent_t> fork_events; hipEvent_t join_event = nullptr; bool side_enabled = true;
+    std::vector<hipEvent_t> fwd_events;        // forward pass: skip-branch convolutions beside the down path (MFVI_FWD_FORK)
     GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
     std::vector<GradFinEntry> fin_uploaded;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
@@ -413,6 +414,7 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     if (plan->samp_dev) (void)hipFree(plan->samp_dev);
     if (plan->drop_dev) (void)hipFree(plan->drop_dev);
     for (auto e : plan->fork_events) (void)hipEventDestroy(e);
+    for (auto e : plan->fwd_events) (void)hipEventDestroy(e);
     if (plan->join_event) (void)hipEventDestroy(plan->join_event);
     if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
@@ -515,6 +517,16 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         if (rc) { set_error("forward: dropout mask launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = (presample && sample_weights) ? plan->n_vi : 0;
+    // A skip-branch convolution (its only consumer is a later concat) on a map of up to MFVI_FWD_FORK pixels (default 64 x 64; 0 = never)
+    // runs on the plan's side stream beside the down path of its scale and is joined in front of that concat: at those sizes both are
+    // latency-bound launches that leave most of the chip idle (3.340 -> 3.329 ms per iteration; forking the 128^2 / 256^2 ones too: 3.335 /
+    // 3.340 — the event pair costs what the overlap saves there).  The side stream exists once a backward pass has run.
+    static const long long fwd_fork = [] { const char* e = getenv("MFVI_FWD_FORK"); return e ? atoll(e) : 4096; }();
+    std::vector<int> join_at(plan->ops.size(), -1); size_t n_fev = 0;
+    auto fwd_event = [&](hipEvent_t* ev) -> hipError_t {
+        if (n_fev == plan->fwd_events.size()) { hipEvent_t e2; const hipError_t e = hipEventCreateWithFlags(&e2, hipEventDisableTiming); if (e != hipSuccess) return e; plan->fwd_events.push_back(e2); }
+        *ev = plan->fwd_events[n_fev++]; return hipSuccess;
+    };
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         const OpInfo& o = plan->ops[i];
         const TensorInfo& y = plan->t[o.d.out];
@@ -522,6 +534,23 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         od.data = (o.d.out == plan->output) ? out : c.farena() + y.act_off; od.sstride = y.numel;
         od.stats = (y.d.has_bn && !plan->bn_eval) ? c.fstats() + y.stats_off : nullptr;
         int rc;
+        hipStream_t stc = st;      // stream of this op
+        if (join_at[i] >= 0) {     // a forked producer of this op's input: wait for it
+            const hipError_t e = hipStreamWaitEvent(st, plan->fwd_events[join_at[i]], 0);
+            if (e != hipSuccess) { set_error("forward: join failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        if (fwd_fork > 0 && plan->side && plan->side_enabled && o.d.type == MFVI_OP_CONV && use_mfma() && (long long)o.g.Ho * o.g.Wo <= fwd_fork &&
+            y.consumers.size() == 1 && y.consumers.front() > (int)i + 1 && plan->ops[y.consumers.front()].d.type == MFVI_OP_CONCAT_UP) {
+            hipEvent_t ef;
+            hipError_t e = fwd_event(&ef);
+            if (e == hipSuccess) e = hipEventRecord(ef, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(plan->side, ef, 0);
+            if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+            stc = plan->side;
+        }
+        hipStream_t st_main = st; (void)st_main;
+        {
+        hipStream_t st = stc;      // (shadows the caller's stream for this op's launches)
         ProfScope ps(plan, (int)i, PASS_FWD, st);
         if (o.d.type == MFVI_OP_CONV_LRT) {
             // LRTLayer.forward (reparam_layers.py:59-72): act_mu = conv(v, mu, mu_b); training: + sqrt(1e-16 + conv(v^2, sigma^2, sigma_b^2)) * eps
@@ -544,6 +573,14 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
             rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
         }
         if (rc) { if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc)); return rc; }
+        }
+        if (stc != st) {           // forked: its completion event, waited for in front of the consumer
+            hipEvent_t ej;
+            hipError_t e = fwd_event(&ej);
+            if (e == hipSuccess) e = hipEventRecord(ej, stc);
+            if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+            join_at[y.consumers.front()] = (int)n_fev - 1;
+        }
     }
     return 0;
 }
