@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/prof_r02; rm -rf $OUT; mkdir -p $OUT
 R=$(pwd)
 export MFVI_TUNE_CACHE=$R/$OUT/tunes_cfg2.json      # absolute: the profiled commands run from /tmp
-python3 bench.py --steps 30 > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
+python3 bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $R/$OUT/kernel_stats_cfg2.csv
@@ -24,7 +24,7 @@ unset MFVI_TUNE_CACHE
 rm -f $OUT/pmc_sq_up9.txt; scripts/dev/pmc_sq.sh $OUT/pmc_sq_up9.txt 36 16 3 1 256 256
 for c in cfg1 cfg3 cfg4 cfg5 inp; do
   export MFVI_TUNE_CACHE=$R/$OUT/tunes_$c.json
-  python3 bench.py --config $c --steps 10 > $OUT/bench_$c.json 2> /dev/null
+  python3 bench.py --config $c > $OUT/bench_$c.json 2> /dev/null
   (cd /tmp && rm -rf /tmp/p_$c && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$c -- python3 $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1)
   cp $(find /tmp/p_$c -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$c.csv
   echo "done $c"
