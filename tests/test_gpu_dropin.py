@@ -230,3 +230,33 @@ def test_fusednet_plain_nets_follow_the_reference_loops(M, golden_dir, method):
             d.eval()
         a = net(z).detach(); b = net(z).detach()
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode,H,W", [("nearest", 36, 44), ("bilinear", 36, 44), ("nearest", 35, 45), ("bilinear", 35, 45), ("nearest", 33, 47)])
+def test_fusednet_odd_sizes_against_plain_torch(M, mode, H, W):
+    """Sizes that are not multiples of 2^scales: `Concat` centre-crops the up-sampled branch (models/common.py:31-41).  The same module tree
+    runs as plain PyTorch on the CPU in float64 (get_net builds ordinary nn.Modules; its Concat crops as the reference's does) and through
+    FusedNet on the HIP kernels: forward and every convolution's weight gradient agree — an oracle-independent check of the cropped
+    up-sampling and its adjoint, in both up-sampling modes, including odd widths (generic fp32 kernels).
+    Gradients: LeakyReLU's kink makes any float32 run (PyTorch's own included: 4.6e-2 from its float64 run at seed 3, 35 x 45, where the HIP
+    result is within 2e-6) jump when one BatchNorm output lies within rounding of zero, and the deepest BatchNorm here normalises over 5 x 6
+    pixels; hence float64 as the arbiter, a tight relative L2 bound and a loose max-norm one (scripts/dev/odd_probe.py sweeps seeds)."""
+    torch.manual_seed(4)
+    mk = lambda: M.get_net(8, 'skip', 'reflection', mode, n_channels=2, skip_n33d=[8, 16, 16], skip_n33u=[8, 16, 16], skip_n11=4, num_scales=3)
+    ref32 = mk()
+    ref = mk().double(); ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in ref32.state_dict().items()})
+    base = mk(); base.load_state_dict(ref32.state_dict())
+    hip = M.FusedNet(base, device=torch.device('cuda'), seed=1)
+    x = torch.rand(1, 8, H, W) * 0.1
+    o_ref = ref(x.double())
+    o_hip = hip(x.cuda())
+    assert tuple(o_hip.shape) == tuple(o_ref.shape) == (1, 2, H, W)
+    assert relerr(o_hip.detach().cpu().numpy(), o_ref.detach().numpy()) < 2e-5
+    g = torch.randn(o_ref.shape)
+    o_ref.backward(g.double()); o_hip.backward(g.cuda())
+    cr = [m for m in ref.modules() if isinstance(m, torch.nn.Conv2d)]
+    ch = [m for m in hip.modules() if isinstance(m, torch.nn.Conv2d)]
+    assert len(cr) == len(ch) > 0
+    for a, b in zip(cr, ch):
+        ga, gb = a.weight.grad.numpy(), b.weight.grad.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(gb - ga) < 5e-3 * np.linalg.norm(ga) and relerr(gb, ga) < 5e-2, (mode, tuple(a.weight.shape))
