@@ -84,7 +84,7 @@ void mfvi_plan_destroy(mfvi_plan* plan);
  * "dy of this layer is final" on the caller's stream, joined before the gradient reduction), so they overlap the backward-data /
  * fold chain that carries the critical path.  Results are unchanged.  enabled = 0 keeps every launch on the caller's stream
  * (e.g. to time a kernel alone); MFVI_SIDE_STREAM=0 in the environment does the same for every plan.  Once that stream exists,
- * mfvi_forward uses it too: a skip-branch convolution on a small map (<= MFVI_FWD_FORK pixels, default 64 x 64; 0 = never) runs there
+ * mfvi_forward uses it too: a skip-branch convolution on a small map (<= MFVI_FWD_FORK pixels, default 128 x 128; 0 = never) runs there
  * beside the down path of its scale and is joined in front of its concat. */
 int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled);
 /* Dropout2d layers of the program are active by default (the reference keeps its MC-dropout nets in train mode);

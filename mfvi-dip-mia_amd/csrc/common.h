@@ -1,7 +1,22 @@
 // Shared device/host definitions of libmfvi_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+
+// A kernel launch that carries a pending "stop" event on its own dispatch packet (hipExtLaunchKernelGGL): mfvi_backward arms the event in
+// front of the last launch on the caller's stream before it forks work onto the side stream, so the fork costs that stream no marker
+// packet of its own (scripts/micro/fork_gap.hip: hipEventRecord + hipStreamWaitEvent add 5.1 us to the recording stream per fork, the
+// event on the kernel's packet 1.8 us).  Not armed (the normal case, and every launch outside mfvi_backward): a plain launch.
+extern thread_local hipEvent_t mfvi_tl_stop_event;
+template <typename F, typename... Args>
+inline void mfvi_launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args)
+{
+    if (mfvi_tl_stop_event) {
+        hipEvent_t e = mfvi_tl_stop_event; mfvi_tl_stop_event = nullptr;
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, nullptr, e, 0, args...);
+    } else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
 
 #define MFVI_MAX_C 256           // max channels of any activation tensor handled by the kernels
 

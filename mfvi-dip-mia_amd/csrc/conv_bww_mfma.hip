@@ -701,7 +701,7 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
         strips = (n_tiles + tpb - 1) / tpb;
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bww_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (attr != hipSuccess) return (int)attr;
-        hipLaunchKernelGGL(conv_bww_split_kernel, dim3(strips * co_tiles * ci_groups * n_samples), dim3(512), lds_bytes, st, in, gy, g, part.base,
+        mfvi_launch(conv_bww_split_kernel, dim3(strips * co_tiles * ci_groups * n_samples), dim3(512), lds_bytes, st, in, gy, g, part.base,
                            part.stride, tiles_x, n_tiles, tpb, ci_groups, strips, co_tiles * ci_groups, n_samples);
         if (strips_used) *strips_used = strips;
         return (int)hipGetLastError();
@@ -728,7 +728,7 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (attr != hipSuccess) return (int)attr;                                                                          \
         }                                                                                                                      \
-        hipLaunchKernelGGL(kern, dim3(strips * co_tiles * ci_groups * n_samples), dim3(NT_), lds_bytes, st, in, gy, g, part.base, \
+        mfvi_launch(kern, dim3(strips * co_tiles * ci_groups * n_samples), dim3(NT_), lds_bytes, st, in, gy, g, part.base, \
                            part.stride, tiles_x, n_tiles, tpb, ci_groups, strips, co_tiles * ci_groups, n_samples);            \
         if (strips_used) *strips_used = strips;                                                                                \
         return (int)hipGetLastError();                                                                                         \

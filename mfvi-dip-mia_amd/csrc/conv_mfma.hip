@@ -1096,12 +1096,12 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (lds_big + ws_bytes > 150 * 1024) big = false;                                                              \
             A.tiles_per_block = T;                                                                                         \
             A.nx = (A.n_tiles + T - 1) / T; A.ny = my; A.nz = n_samples;                                                   \
-            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
-            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
-            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
-            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
-            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
-            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            if (rem) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (ff && big) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (ff) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (big) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else if (ph) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
+            else mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, true, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ws_bytes + chan_bytes, st, A); \
         } else {                                                                                                           \
             /* chunked weights: one tile per block, except for the fused fold on rectangular tiles, whose producer-side fold of tile i   \
                overlaps the stages of tile i+1 (the weights of a stage are re-read from L2 per tile) */                                   \
@@ -1111,12 +1111,12 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
             if (big) ck_bytes = ck_big;                                                                                    \
             A.tiles_per_block = multi ? T : 1;                                                                             \
             A.nx = (A.n_tiles + A.tiles_per_block - 1) / A.tiles_per_block; A.ny = my; A.nz = n_samples;                   \
-            if (rem) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
-            else if (ff && big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
-            else if (ff) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
-            else if (big) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
-            else if (ph) hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
-            else hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            if (rem) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_REM, CAN_REM>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (ff && big) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG, false, CAN_FF && CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (ff) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, false, CAN_FF>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (big) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, CAN_BIG>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else if (ph) mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_, false, CAN_PH>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
+            else mfvi_launch((conv_mfma_kernel<KS, STRIDE, MF_, TH_, MODE, false, FL_>), dim3(A.nx * A.ny * A.nz), dim3(512), ck_bytes + chan_bytes, st, A); \
         }                                                                                                                  \
         return (int)hipGetLastError();                                                                                     \
     }

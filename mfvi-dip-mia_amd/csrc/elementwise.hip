@@ -587,13 +587,13 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
     for (int i = 0; i < n_src; ++i) { if (srcs[i].pad > maxpad) maxpad = srcs[i].pad; any_mul |= srcs[i].mul2v; }      // the float4 kernel folds pad <= 1
     if (n_src <= 2 && !any_mul && maxpad <= 1 && (x.W & 3) == 0 && x.H >= 2 && ((x.sstride | ga_sstride) & 3) == 0 && al16(x.data) && al16(ga)) {
         dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), x.C, n_samples);
-        hipLaunchKernelGGL(finalize_dx_vec_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
+        mfvi_launch(finalize_dx_vec_kernel, grid, dim3(256), 0, st, s0, s1, n_src, x, ga, ga_sstride, bsums);
         return (int)hipGetLastError();
     }
     dim3 grid((unsigned)((HW + 256 * EW_ITEMS - 1) / (256 * EW_ITEMS)), x.C, n_samples);
     FoldSrcs S; S.n = n_src;
     for (int i = 0; i < MAX_FOLD_SRC; ++i) S.s[i] = srcs[i < n_src ? i : 0];
-    hipLaunchKernelGGL(finalize_dx_kernel, grid, dim3(256), 0, st, S, x, ga, ga_sstride, bsums);
+    mfvi_launch(finalize_dx_kernel, grid, dim3(256), 0, st, S, x, ga, ga_sstride, bsums);
     return (int)hipGetLastError();
 }
 
@@ -655,7 +655,7 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
     const int tiles_x = (b.W + CB_TW - 1) / CB_TW, tiles_y = (b.H + CB_TH - 1) / CB_TH;
     dim3 grid((unsigned)(tiles_x * tiles_y), Ct, n_samples);
     TView av = a ? *a : b;
-    hipLaunchKernelGGL(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
+    mfvi_launch(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
                        ga_b_sstride, bsums_b, tiles_x, nearest, pairs);
     return (int)hipGetLastError();
 }

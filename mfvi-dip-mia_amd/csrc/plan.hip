@@ -19,6 +19,8 @@ void set_error(const char* fmt, ...)
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 
+thread_local hipEvent_t mfvi_tl_stop_event = nullptr;      // see mfvi_launch (common.h)
+
 namespace {
 
 struct TensorInfo {
@@ -517,16 +519,26 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         if (rc) { set_error("forward: dropout mask launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = (presample && sample_weights) ? plan->n_vi : 0;
-    // A skip-branch convolution (its only consumer is a later concat) on a map of up to MFVI_FWD_FORK pixels (default 64 x 64; 0 = never)
+    // A skip-branch convolution (its only consumer is a later concat) on a map of up to MFVI_FWD_FORK pixels (default 128 x 128; 0 = never)
     // runs on the plan's side stream beside the down path of its scale and is joined in front of that concat: at those sizes both are
-    // latency-bound launches that leave most of the chip idle (3.340 -> 3.329 ms per iteration; forking the 128^2 / 256^2 ones too: 3.335 /
-    // 3.340 — the event pair costs what the overlap saves there).  The side stream exists once a backward pass has run.
-    static const long long fwd_fork = [] { const char* e = getenv("MFVI_FWD_FORK"); return e ? atoll(e) : 4096; }();
+    // latency-bound launches that leave most of the chip idle (with the events on the kernels' packets: 3.306 ms per iteration without,
+    // 3.282 / 3.274 / 3.279 with the maps up to 64^2 / 128^2 / 256^2).  The side stream exists once a backward pass has run.
+    static const long long fwd_fork = [] { const char* e = getenv("MFVI_FWD_FORK"); return e ? atoll(e) : 16384; }();
     std::vector<int> join_at(plan->ops.size(), -1); size_t n_fev = 0;
     auto fwd_event = [&](hipEvent_t* ev) -> hipError_t {
         if (n_fev == plan->fwd_events.size()) { hipEvent_t e2; const hipError_t e = hipEventCreateWithFlags(&e2, hipEventDisableTiming); if (e != hipSuccess) return e; plan->fwd_events.push_back(e2); }
         *ev = plan->fwd_events[n_fev++]; return hipSuccess;
     };
+    auto forks = [&](size_t j) {
+        if (j >= plan->ops.size()) return false;
+        const OpInfo& oj = plan->ops[j]; const TensorInfo& yj = plan->t[oj.d.out];
+        return fwd_fork > 0 && plan->side && plan->side_enabled && oj.d.type == MFVI_OP_CONV && use_mfma() && (long long)oj.g.Ho * oj.g.Wo <= fwd_fork &&
+               yj.consumers.size() == 1 && yj.consumers.front() > (int)j + 1 && plan->ops[yj.consumers.front()].d.type == MFVI_OP_CONCAT_UP;
+    };
+    // events on the kernels' own packets where the launch goes through mfvi_launch (as in mfvi_backward): the fork event of op i + 1 on op i's
+    // launch, the join event on the forked launch itself
+    static const bool on_packet = [] { const char* e = getenv("MFVI_FORK_ON_PACKET"); return !(e && e[0] == '0'); }();
+    hipEvent_t pre_ev = nullptr; size_t pre_for = (size_t)-1; bool pre_done = false; int pre_idx = -1;
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         const OpInfo& o = plan->ops[i];
         const TensorInfo& y = plan->t[o.d.out];
@@ -539,14 +551,27 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
             const hipError_t e = hipStreamWaitEvent(st, plan->fwd_events[join_at[i]], 0);
             if (e != hipSuccess) { set_error("forward: join failed: %s", hipGetErrorString(e)); return (int)e; }
         }
-        if (fwd_fork > 0 && plan->side && plan->side_enabled && o.d.type == MFVI_OP_CONV && use_mfma() && (long long)o.g.Ho * o.g.Wo <= fwd_fork &&
-            y.consumers.size() == 1 && y.consumers.front() > (int)i + 1 && plan->ops[y.consumers.front()].d.type == MFVI_OP_CONCAT_UP) {
-            hipEvent_t ef;
-            hipError_t e = fwd_event(&ef);
-            if (e == hipSuccess) e = hipEventRecord(ef, st);
+        if (forks(i)) {
+            hipEvent_t ef = nullptr;
+            hipError_t e = hipSuccess;
+            if (pre_for == i) { ef = pre_ev; if (!pre_done) e = hipEventRecord(ef, st); }      // reserved on the previous launch (recorded there, or here if that launch took another path)
+            else { e = fwd_event(&ef); if (e == hipSuccess) e = hipEventRecord(ef, st); }
             if (e == hipSuccess) e = hipStreamWaitEvent(plan->side, ef, 0);
             if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
             stc = plan->side;
+        }
+        pre_for = (size_t)-1;
+        hipEvent_t ej = nullptr; int ej_idx = -1; bool armed = false;
+        if (stc != st) {           // forked: its completion event rides on its own launch
+            const hipError_t e = fwd_event(&ej);
+            if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+            ej_idx = (int)n_fev - 1;
+            if (on_packet && plan->prof_mode != 1) { mfvi_tl_stop_event = ej; armed = true; }
+        } else if (on_packet && plan->prof_mode != 1 && o.d.type != MFVI_OP_CONV_LRT && forks(i + 1)) {
+            const hipError_t e = fwd_event(&pre_ev);
+            if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+            pre_for = i + 1; pre_idx = (int)n_fev - 1; (void)pre_idx;
+            mfvi_tl_stop_event = pre_ev; armed = true;
         }
         hipStream_t st_main = st; (void)st_main;
         {
@@ -572,15 +597,17 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
             rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
         }
-        if (rc) { if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc)); return rc; }
+        if (rc) { mfvi_tl_stop_event = nullptr; if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc)); return rc; }
         }
+        const bool consumed = armed && mfvi_tl_stop_event == nullptr;      // the event went out on the launch's packet
+        mfvi_tl_stop_event = nullptr;
         if (stc != st) {           // forked: its completion event, waited for in front of the consumer
-            hipEvent_t ej;
-            hipError_t e = fwd_event(&ej);
-            if (e == hipSuccess) e = hipEventRecord(ej, stc);
-            if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
-            join_at[y.consumers.front()] = (int)n_fev - 1;
-        }
+            if (!consumed) {
+                const hipError_t e = hipEventRecord(ej, stc);
+                if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            join_at[y.consumers.front()] = ej_idx;
+        } else if (pre_for == i + 1) pre_done = consumed;
     }
     return 0;
 }
@@ -644,6 +671,35 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         }
         side = plan->side;
     }
+    // The fork event of the NEXT op's backward-weight kernel rides on the packet of this op's last launch on the caller's stream when that
+    // launch goes through mfvi_launch (armed right before it; a launcher that takes another path leaves it armed and the fork falls back to
+    // hipEventRecord).  MFVI_FORK_ON_PACKET=0: always hipEventRecord.
+    static const bool fork_on_packet = [] { const char* e = getenv("MFVI_FORK_ON_PACKET"); return !(e && e[0] == '0'); }();
+    int armed_idx = -1;
+    auto will_fork = [&](int j) {
+        if (j < 0 || side == st || plan->ops[j].d.type != MFVI_OP_CONV) return false;
+        const OpInfo& oj = plan->ops[j];
+        const bool bww_only_j = (oj.d.in0 == plan->input) && dz == nullptr;
+        return !bww_only_j && (long long)oj.g.Ho * oj.g.Wo <= side_maxpix;
+    };
+    auto arm = [&](int i_cur) -> int {       // call right before the LAST launch of op i_cur on `st`
+        armed_idx = -1; mfvi_tl_stop_event = nullptr;
+        if (!fork_on_packet || plan->prof_mode == 1 || !will_fork(i_cur - 1)) return 0;      // (mode 1 brackets every launch with its own events)
+        if (n_fork == plan->fork_events.size()) {
+            hipEvent_t ev; const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) { set_error("backward: event creation failed: %s", hipGetErrorString(e)); return (int)e; }
+            plan->fork_events.push_back(ev);
+        }
+        mfvi_tl_stop_event = plan->fork_events[n_fork]; armed_idx = (int)n_fork;
+        return 0;
+    };
+    auto settle = [&]() {                     // after that launch: consumed (the event is on the kernel's packet) or not
+        if (mfvi_tl_stop_event) { mfvi_tl_stop_event = nullptr; armed_idx = -1; }
+    };
+    // the join event rides on the side stream's last launch (the backward-weight kernel of the last op that forks)
+    int last_fork_op = -1;
+    for (int j = 0; j < (int)plan->ops.size(); ++j) if (will_fork(j)) { last_fork_op = j; break; }
+    bool join_on_packet = false;
     for (int i = (int)plan->ops.size() - 1; i >= 0; --i) {
         const OpInfo& o = plan->ops[i];
         int rc = 0;
@@ -692,14 +748,19 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                     if (e != hipSuccess) { set_error("backward: event creation failed: %s", hipGetErrorString(e)); return (int)e; }
                     plan->fork_events.push_back(ev);
                 }
-                hipError_t e = hipEventRecord(plan->fork_events[n_fork], st);
+                hipError_t e = hipSuccess;
+                if (armed_idx != (int)n_fork) e = hipEventRecord(plan->fork_events[n_fork], st);      // else: already on the previous launch's packet
                 if (e == hipSuccess) e = hipStreamWaitEvent(sw, plan->fork_events[n_fork], 0);
                 if (e != hipSuccess) { set_error("backward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
                 ++n_fork;
             }
+            armed_idx = -1;
             { ProfScope ps(plan, i, PASS_BWD_WEIGHT, sw);
               int strips = 0;
+              const bool arm_join = fork_on_packet && plan->prof_mode != 1 && sw != st && i == last_fork_op;
+              if (arm_join) mfvi_tl_stop_event = plan->join_event;
               rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips, n_samples, sw) : -2;
+              if (arm_join) { join_on_packet = mfvi_tl_stop_event == nullptr; mfvi_tl_stop_event = nullptr; }
               if (rc == 0) {
                   GradFinEntry e{};
                   e.w_off = o.g.w_off; e.b_off = o.g.b_off; e.part_off = o.part_off; e.stride = o.part_stride;
@@ -722,16 +783,24 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                     FoldFuse ff; ff.x = xin; ff.ga = (o.d.in0 == plan->input) ? dz : c.farena() + x.ga_off; ff.ga_sstride = x.numel;
                     ff.bsums = x.d.has_bn ? c.bsums() + x.stats_off : nullptr;
                     ProfScope ps(plan, i, PASS_BWD_DATA, st);
+                    { const int ra = arm(i); if (ra) return ra; }
                     const int r2 = launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, nullptr, 0, n_samples, st, &ff);
-                    if (r2 == 0) folded = true; else if (r2 != -2 && r2 != -3) rc = r2;
+                    settle();
+                    if (r2 == 0) folded = true; else { armed_idx = -1; if (r2 != -2 && r2 != -3) rc = r2; }
                 }
+                const bool fold_here = x.consumers.front() == i;
                 if (!rc && !folded) {
                   ProfScope ps(plan, i, PASS_BWD_DATA, st);
+                  if (!fold_here) { const int ra = arm(i); if (ra) return ra; }      // no fold behind it: this is the op's last launch on `st`
                   rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, c.farena() + o.scratch_off, per, n_samples, st) : -2;
+                  if (!fold_here) { settle(); if (rc) armed_idx = -1; }
                   if ((rc == -2 || rc == -3) && !mu) { set_error("backward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table", i); rc = -1; }
                   if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
-                if (!rc && !folded && x.consumers.front() == i)           // all consumers of in0 have run: fold + act' + BN sums
+                if (!rc && !folded && fold_here) {         // all consumers of in0 have run: fold + act' + BN sums
+                    { const int ra = arm(i); if (ra) return ra; }
                     rc = fold_consumers(plan, c, o.d.in0, xin, dz, sample_weights, i, n_samples, st);
+                    settle();
+                }
             }
         } else {
             const GView gc = c.gview(o.d.out, dout);
@@ -742,17 +811,20 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                 a = c.view(o.d.in0); ga_a = c.farena() + ta.ga_off; sa = ta.numel; bs_a = ta.d.has_bn ? c.bsums() + ta.stats_off : nullptr;
             }
             ProfScope ps(plan, i, PASS_CONCAT_BWD, st);
+            { const int ra = arm(i); if (ra) return ra; }
             rc = launch_concat_up_bwd(gc, o.d.in0 >= 0 ? &a : nullptr, ga_a, sa, bs_a, c.view(o.d.in1), c.farena() + b.ga_off, b.numel,
                                       b.d.has_bn ? c.bsums() + b.stats_off : nullptr, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
+            settle();
         }
         if (rc) {
+            mfvi_tl_stop_event = nullptr;
             if (rc > 0) set_error("backward: op %d launch failed: %s", i, hipGetErrorString((hipError_t)rc));
             if (side != st) (void)hipStreamSynchronize(side);   // leave no side-stream work behind a failed call
             return rc;
         }
     }
     if (side != st) {        // join: grad_finalize (and the caller) see every partial slab / accumulated gradient
-        hipError_t e = hipEventRecord(plan->join_event, side);
+        hipError_t e = join_on_packet ? hipSuccess : hipEventRecord(plan->join_event, side);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, plan->join_event, 0);
         if (e != hipSuccess) { set_error("backward: join failed: %s", hipGetErrorString(e)); return (int)e; }
     }
