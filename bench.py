@@ -222,10 +222,10 @@ def main():
         gt = phantom(S, S, cfg["hp"]["seed"])
         book = _Book(eng, 16, gt, eng.target.cpu().numpy())
         for i in range(3):
-            eng.step(); book.iteration(eng, i, eng.chunk)
+            eng.step(after_forward=book.hook(eng, i, eng.chunk))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(3, 13):
-            eng.step(); book.iteration(eng, i, eng.chunk)
+            eng.step(after_forward=book.hook(eng, i, eng.chunk))
         torch.cuda.synchronize(); with_book = 10 / (time.perf_counter() - t0)
 
     # ---- timed region: exactly --steps iterations, only the dominant kernel carries events ----

@@ -145,7 +145,7 @@ class ElboEngine:
             L.check(lib.mfvi_radon_mse(L.ptr(self.out), L.ptr(self.target), L.ptr(self.theta), n, self.H, self.W, self.theta.numel(), scale,
                                        L.ptr(self.ct_scratch), L.ptr(self.dout), L.ptr(self.acc), sp))
 
-    def grad_only(self, step=None, perturb=True, with_kl=True):
+    def grad_only(self, step=None, perturb=True, with_kl=True, after_forward=None):
         """Everything of one iteration except the optimizer update; returns nothing (grads, acc hold the result)."""
         lib, sp = L.lib(), L.stream_ptr()
         step = self.t if step is None else step
@@ -158,6 +158,8 @@ class ElboEngine:
             n = min(self.chunk, self.K_local - c0)
             self.plan.forward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.sample_weights, self.out)
             self._loss_and_dout(n)
+            if after_forward is not None and c0 + n >= self.K_local:
+                after_forward()        # self.out of the last launch is final in stream order here: work that only reads it can overlap the backward pass
             self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn,
                                self.sample_weights)
         if self.world > 1:
@@ -183,11 +185,12 @@ class ElboEngine:
         L.check(lib.mfvi_bf16_to_f32(L.ptr(self.rho), self.n_vi, L.ptr(out[self.n_vi:]), sp))
         return out[:self.n_vi], out[self.n_vi:], self.bn
 
-    def step(self):
+    def step(self, after_forward=None):
         """One ELBO iteration: K forwards + NLL + backward + (all-reduce), then KL + its gradient + Adam in one fused launch
-        (identical on every rank: no communication)."""
+        (identical on every rank: no communication).  after_forward: optional callable run once the last forward + data term of the
+        iteration are enqueued (the runners start their per-iteration bookkeeping there, on a second stream beside the backward pass)."""
         lib, sp = L.lib(), L.stream_ptr()
-        self.grad_only(self.t, with_kl=False)
+        self.grad_only(self.t, with_kl=False, after_forward=after_forward)
         self.t += 1
         if self.param_dtype == "bf16":
             L.check(lib.mfvi_elbo_update_bf16(L.ptr(self.mu), L.ptr(self.rho), L.ptr(self.bn), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi,
@@ -283,11 +286,11 @@ class SiblingEngine(ElboEngine):
             n = lay["cout"] * lay["cin"] * lay["k"] * lay["k"]
             L.check(lib.mfvi_add_normal(L.ptr(self.mu[lay["w_off"]:]), self.seed, lid, step, n, std, sp))
 
-    def step(self):
+    def step(self, after_forward=None):
         lib, sp = L.lib(), L.stream_ptr()
         if self.method == METHOD_SGLD:
             self.add_noise(self.t)
-        self.grad_only(self.t, with_kl=False)
+        self.grad_only(self.t, with_kl=False, after_forward=after_forward)
         self.t += 1
         n = self.n_vi
         for lo, hi in ((0, n), (2 * n, self.n_params)):          # MU block and BN block; RHO does not exist for these methods

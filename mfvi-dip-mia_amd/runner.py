@@ -62,7 +62,32 @@ def _load_image(img, imsize, seed):
     return np.ascontiguousarray(a[:h - h % 32, :w - w % 32])                     # crop to a multiple of 32 (get_image: d=32)
 
 
-class _Book:
+class _AsyncBook:
+    """The per-iteration bookkeeping only READS the iteration's forward output, so it runs on a second stream beside the backward pass:
+    `eng.step(after_forward=book.hook(eng, i, n))` enqueues it behind the forward, `book.wait()` (called by the next hook and by snapshot /
+    results) orders the caller's stream behind it before `eng.out` is written again."""
+    _side = None; _done = None
+
+    def hook(self, eng, i, n):
+        def run():
+            t = self.t
+            if self._side is None:
+                self._side = t.cuda.Stream(); self._done = t.cuda.Event()
+            main = t.cuda.current_stream()
+            ready = t.cuda.Event(); ready.record(main)
+            with t.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                self.iteration(eng, i, n)
+                self._done.record(self._side)
+        self.wait()          # the previous iteration's bookkeeping has read eng.out before this iteration's forward overwrites it
+        return run
+
+    def wait(self):
+        if self._done is not None:
+            self.t.cuda.current_stream().wait_event(self._done)
+
+
+class _Book(_AsyncBook):
     """Device-side bookkeeping state of one den / sr / ct fit (bayesian_optimization.py:1374-1416, :2190-2236, :584-626).
     Column 0 of mse_noisy / psnrs / ssims is the 'corrupted' reference of the task: the noisy image (den), the low-resolution image
     against the [::f, ::f] projection of the output (sr: downsampler(out_avg) / out_lr, :2203-2218), the ground truth (ct)."""
@@ -112,6 +137,7 @@ class _Book:
         L.check(lib.mfvi_ssim_sum(p(self.gt), p(self.avg_clip), self.H, self.W, p(m[7:]), sp))
 
     def snapshot(self):
+        self.wait()
         lib, sp, p = L.lib(), L.stream_ptr(), L.ptr
         L.check(lib.mfvi_ring_stats(p(self.ring_epi), MC_ITER, self.H, self.W, p(self.var), None, sp))
         if self.C > 1:
@@ -119,6 +145,7 @@ class _Book:
         return self.var.cpu().numpy(), self.ale_mean.cpu().numpy(), self.avg_clip.cpu().numpy()
 
     def results(self):
+        self.wait()
         m = self.metrics.cpu().numpy(); hw = float(self.H * self.W)
         n = np.full(8, hw)
         if self.task == "sr":
@@ -129,11 +156,12 @@ class _Book:
         return m[:, 0], m[:, 1], psnrs, m[:, 5:8]
 
 
-class _BookInp:
+class _BookInp(_AsyncBook):
     """Device-side bookkeeping of the inpainting runner (bayesian_optimization.py:3039-3090): sigmoid colour channels, masked PSNR / SSIM."""
 
     def __init__(self, eng, num_iter, img, mask):
         import torch
+        self.t = torch
         dev = "cuda"
         H, W = eng.H, eng.W
         self.H, self.W = H, W
@@ -164,6 +192,7 @@ class _BookInp:
             L.check(lib.mfvi_ssim_sum(p(self.img_m[c]), p(self.avg_m[c]), H, W, p(m[6, c:]), sp))
 
     def snapshot(self):
+        self.wait()
         lib, p, sp = L.lib(), L.ptr, L.stream_ptr()
         for c in range(3):
             L.check(lib.mfvi_ring_stats(p(self.ring_epi[:, c].contiguous()), MC_ITER, self.H, self.W, p(self.var[c]), None, sp))
@@ -171,6 +200,7 @@ class _BookInp:
         return self.var.cpu().numpy(), self.ale_mean.cpu().numpy(), self.avg_clip.cpu().numpy()
 
     def results(self):
+        self.wait()
         mt = self.metrics.cpu().numpy().mean(axis=2) / (self.H * self.W)      # mean over the colour channels == mean over all 3*H*W elements
         with np.errstate(divide="ignore"):
             psnrs = 10.0 * np.log10(1.0 / mt[:, 1:4])
@@ -229,8 +259,9 @@ def _run(task, img, imsize, p_sigma, num_iter, lr, temp, sigma, input_depth, see
     recons = np.zeros((n_snap, 1, H, W)); uncerts_epi = np.zeros((n_snap, 1, H, W)); uncerts_ale = np.zeros((n_snap, 1, H, W))
     t0 = time.perf_counter()
     for i in range(num_iter):
-        eng.step()                                                    # one fused ELBO iteration (a non-finite loss skips the update on the device: engine.step)
-        book.iteration(eng, i, eng.chunk)
+        # one fused ELBO iteration (a non-finite loss skips the update on the device: engine.step); the bookkeeping of :1374-1406 reads only the
+        # iteration's forward output and runs on a second stream beside the backward pass
+        eng.step(after_forward=book.hook(eng, i, eng.chunk))
         if i % show_every == 0:
             var, ale, recon = book.snapshot()
             uncerts_epi[i // show_every, 0] = var; uncerts_ale[i // show_every, 0] = ale; recons[i // show_every, 0] = recon
@@ -349,8 +380,7 @@ def run_inp_mfvi(img="phantom", mask=None, imsize=(256, 256), num_iter=5000, lr=
     recons = np.zeros((n_snap, 3, H, W)); uncerts_epi = np.zeros((n_snap, 3, H, W)); uncerts_ale = np.zeros((n_snap, 1, H, W))
     t0 = time.perf_counter()
     for i in range(num_iter):
-        eng.step()
-        book.iteration(eng, i, eng.chunk)
+        eng.step(after_forward=book.hook(eng, i, eng.chunk))
         if i % show_every == 0:
             var, ale, recon = book.snapshot()
             uncerts_epi[i // show_every] = var; uncerts_ale[i // show_every, 0] = ale; recons[i // show_every] = recon

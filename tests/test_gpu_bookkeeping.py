@@ -238,3 +238,26 @@ def test_dropin_gaussian_nll_functions(M, golden_dir):
     from mfvi_dip_mia_amd import bayes
     src = inspect.getsource(bayes.gaussian_nll) + inspect.getsource(bayes._GaussianNLL)
     assert "torch.exp" not in src and "torch.clamp" not in src       # the arithmetic is in libmfvi_hip, not ATen
+
+
+def test_bookkeeping_beside_the_backward_pass_equals_the_serial_order(M):
+    """The runners start the per-iteration bookkeeping behind the forward pass on a second stream (`eng.step(after_forward=book.hook(...))`),
+    beside the backward pass: same kernels, same inputs — every stored metric and the snapshot equal those of bookkeeping after the step
+    (to the last bits only: two training runs differ there through the summation order of the BatchNorm statistics' atomics)."""
+    from mfvi_dip_mia_amd.engine import ElboEngine
+    from mfvi_dip_mia_amd.runner import _Book
+    H = W = 64; K, n_it, seed = 2, 7, 11
+    img = O.phantom(H, W, seed); noisy = O.noisy(img, 0.1, seed)
+    res = []
+    for mode in ("serial", "beside"):
+        eng = ElboEngine(H, W, task="den", K=K, temp=5.66e-7, sigma=1.46e-5, lr=1e-3, seed=seed, autotune=False)
+        eng.set_target(torch.from_numpy(noisy))
+        book = _Book(eng, n_it, img, noisy, task="den")
+        for i in range(n_it):
+            if mode == "serial":
+                eng.step(); book.iteration(eng, i, eng.chunk)
+            else:
+                eng.step(after_forward=book.hook(eng, i, eng.chunk))
+        res.append(book.results() + book.snapshot())
+    for a, b in zip(*res):
+        assert relerr(np.asarray(a, np.float64), np.asarray(b, np.float64)) < 1e-5
