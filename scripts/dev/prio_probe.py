@@ -17,7 +17,7 @@ try:
     print("priority range", torch.cuda.Stream.priority_range())
 except Exception as e:
     print("no priority_range:", e)
-for rep in range(2):
-    print("default stream           : %.4f ms" % run(None))
-    print("own stream, priority  0  : %.4f ms" % run(torch.cuda.Stream(priority=0)))
-    print("own stream, priority -1  : %.4f ms" % run(torch.cuda.Stream(priority=-1)))
+for rep in range(int(os.environ.get("REPS", "2"))):
+    print("default stream           : %.4f ms" % run(None), flush=True)
+    print("own stream, priority  0  : %.4f ms" % run(torch.cuda.Stream(priority=0)), flush=True)
+    print("own stream, priority -1  : %.4f ms" % run(torch.cuda.Stream(priority=-1)), flush=True)
