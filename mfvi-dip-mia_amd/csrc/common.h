@@ -355,6 +355,13 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
 struct FoldFuse { TView x; float* ga = nullptr; long long ga_sstride = 0; double* bsums = nullptr; };
 int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w, long long wstride, float* dxp, long long dxp_sstride,
                               int n_samples, hipStream_t st, const FoldFuse* fuse = nullptr);
+// Row-phase kernels for 3x3 stride-1 layers on maps whose width is a multiple of 64 (conv_rp.hip).  tune = mf | r << 8 | rem << 12 | T << 16
+// (output fragments per block, rows per wave, 4 extra channels on the 4x4x1 instruction, tiles per block); -2: shape not served, -3: tiling
+// not valid for the shape.  Backward-data always runs the fold of the input tensor in its epilogue (fuse.ga required).
+#define MFVI_TUNE_RP (1 << 24)
+int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st);
+int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse);
+int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not served / disabled (MFVI_RP=0)
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
 // bf16: mu / rho point to bf16_t arrays; sample = 0 writes W = mu (RTLayer's eval branch) — callers then launch it for ONE sample

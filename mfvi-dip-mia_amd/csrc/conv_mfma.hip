@@ -1180,6 +1180,13 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
     if ((long long)g.Cout * g.Ho * g.Wo >= (1LL << 31)) return -2;          // the epilogue uses 32-bit element offsets per sample
     // aligned float4 staging: image rows, sample strides and the base pointer must be multiples of 4 floats
     if ((g.W & 3) || g.W < 4 || (in.sstride & 3) || ((uintptr_t)in.data & 15)) return -2;
+    {   // row-phase kernels (conv_rp.hip): an explicit tiling of the plan / autotuner, or the default for the shapes they serve
+        const int tn = g.tune[0] ? g.tune[0] : (env_tune() ? 0 : rp_default_tune(g, 0, n_samples));
+        if (tn & MFVI_TUNE_RP) {
+            const int rc = launch_conv_fwd_rp(in, g, w, wstride, out, tn & (MFVI_TUNE_RP - 1), n_samples, st);
+            if (rc != -2 || g.tune[0]) return rc == -2 ? -3 : rc;
+        }
+    }
     GView none{};
     if (g.ks == 3 && g.stride == 1) return launch_variant<3, 1, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
     if (g.ks == 3 && g.stride == 2) return launch_variant<3, 2, 0>(in, none, g, w, wstride, out, nullptr, 0, n_samples, st);
@@ -1202,6 +1209,13 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
         if (!(g.ks == 1 || (g.ks == 3 && g.stride == 1)) || !fuse->ga || (g.W & 3) || (fuse->ga_sstride & 3) || ((uintptr_t)fuse->ga & 15)) return -2;
         if (fuse->bsums && ((fuse->x.sstride & 3) || ((uintptr_t)fuse->x.data & 15))) return -2;
         if (g.ks == 3 && (g.H < 4 || g.W < 4)) return -2;      // rows 1 and H-2 (columns 1 and W-2) must be distinct, interior lines
+        if (g.ks == 3) {
+            const int tn = g.tune[1] ? g.tune[1] : (env_tune() ? 0 : rp_default_tune(g, 1, n_samples));
+            if (tn & MFVI_TUNE_RP) {
+                const int rc = launch_conv_bwd_data_rp(gy, g, w, wstride, tn & (MFVI_TUNE_RP - 1), n_samples, st, *fuse);
+                if (rc != -2 || g.tune[1]) return rc == -2 ? -3 : rc;
+            }
+        }
         if (g.ks == 3) return launch_variant<3, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
         return launch_variant<1, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
     }

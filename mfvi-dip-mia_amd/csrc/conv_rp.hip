@@ -1,0 +1,596 @@
+// K1 / K2a' for the 3x3 stride-1 layers on maps >= 64 wide — "row-phase" operand layout (round 3).
+//
+// Same implicit GEMM on v_mfma_f32_16x16x4_f32 as conv_mfma.hip (fp32 in / fp32 accumulate, BayTorch/modules/reparam_layers.py:26-37 with
+// the ReflectionPad2d(1) of models/common.py:100-135 in the index math), but the pixel operand is laid out so that ONE wide LDS read
+// feeds twelve matrix instructions instead of one:
+//
+//   a pixel fragment's 16 columns (n = lane & 15) are NOT 16 consecutive pixels; lane n stands for the pixel QUAD 4n .. 4n+3 of a 64-pixel
+//   row segment, and fragment j (the "phase", j = 0..3) holds pixel 4n + j.  Lane (k = lane >> 4, n) reads the six consecutive floats
+//   win[4n .. 4n+5] of reduction channel k's window row (ds_read_b128 + ds_read_b64, window column 0 = image column x0 - 1); the operand of
+//   (phase j, tap kx) is element j + kx of those six.  So 2 LDS instructions feed 4 phases x 3 taps = 12 MFMAs (conv_mfma.hip: 12 reads),
+//   the weights of a (4-channel, ky) step are one ds_read_b128 per output fragment (layout [k][m][ky][4]), and a wave that owns R rows of
+//   a 64-wide tile issues 36 * R * MF MFMAs per 4-channel step from 2 (R + 2) + 3 MF LDS reads.
+//
+//   The accumulator layout that falls out of it is store-friendly: register q of (fragment f, row r, phase j) is channel 16 f + 4 (lane >> 4) + q
+//   at pixel 4 n + j, so the four phases of one register index ARE a float4 of one output row — the epilogue stores aligned float4 rows (16
+//   lanes = 256 contiguous bytes per channel) straight from the accumulators; no LDS transpose, no hand-over to the producer waves.
+//
+// MODE 0 forward:       m = cout, k = cin; window = reflection-padded view(x) (deferred BN + LeakyReLU applied by the staging waves)
+// MODE 1 backward-data: m = cin,  k = cout, flipped taps; window = zero-padded dy (BN-backward formed on load); the gradient is formed on the
+//         UN-padded input domain with the adjoint of the reflection padding folded in (rows: two extra tap rows of MFMAs for image rows 1 and
+//         H-2, wave-uniform; columns: one fma on the pixel operand of image columns 1 and W-2), and the epilogue is the fold of the input
+//         tensor: LeakyReLU'(view(x)), BN-backward sums, ga written once (what finalize_dx did as a separate launch in round 1).
+//   REM: the 4 + 16n channels of the skip() concats — the block that owns the last fragments carries the 4 extra output channels on
+//         v_mfma_f32_4x4x1_16B_f32 against the pixel fragments already in registers (as conv_mfma.hip's REM).
+// Block: 512 threads; waves 0-3 issue MFMAs (wave w owns rows w R .. w R + R - 1 of a (4 R) x 64 tile), waves 4-7 stage the next 4-channel
+// window (producer wave p = channel p of the chunk: global float4 -> transform -> ds_write_b128) and the next weight chunk; one barrier per
+// chunk.  Several tiles per block run through the same pipeline.
+#include "common.h"
+#include <type_traits>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 4 floats at dword alignment (window quads start at column x0 - 1)
+
+struct RpArgs {
+    TView xin; GView gin; ConvGeom g;
+    const float* w; long long wstride;     // weights of sample k at w + k*wstride
+    OutDesc out;                           // MODE 0
+    float* fga; long long fga_sstride; double* fbsums;      // MODE 1: gradient wrt the BN output of the input tensor, its BN-backward sums (or nullptr)
+    int tiles_x, n_tiles, tiles_per_block;
+    int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
+};
+
+#ifdef RP_PROF
+// dev build: per-phase s_memtime sums of consumer wave 0 / producer wave 0 of every block (scripts/dev/rp_prof.py)
+__device__ unsigned long long g_rp_prof[16];
+__device__ __forceinline__ unsigned long long rp_now() { unsigned long long t; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define RP_T(v) const unsigned long long v = rp_now()
+#define RP_ACC(slot, d) prof[slot] += (d)
+#else
+#define RP_T(v)
+#define RP_ACC(slot, d)
+#endif
+
+// BN-backward on load in three operations per element: dy = (y - mean) * qc + (ga * c1 + k2), qc = -c1 c3 rstd, k2 = -c1 c2
+// (chan_bwd's  c1 * (ga - c2 - xhat * c3)  with the products of the channel constants formed once per block)
+struct RpBwd { float mean, qc, c1, k2; };
+
+template <int R>
+struct RpCfg {
+    static constexpr int TH = 4 * R, WROWS = TH + 2, NQ = 17, PITCH = 4 * NQ;       // 66 window columns -> 17 quads
+    static constexpr int PLANE = (WROWS * PITCH + 63) / 64 * 64;                    // == 0 (mod 64): the 16-lane groups of a ds_read_b128 hit 64 distinct banks
+    static constexpr int NITEM = WROWS * NQ, NV = (NITEM + 63) / 64;
+};
+
+// MINW: minimum waves per SIMD the register allocation must allow (4 = 128 VGPRs = two 512-thread blocks per CU)
+template <int MODE, int MF, int R, bool REM, int MINW>
+__global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
+{
+    static_assert(!REM || MODE == 1, "remainder channels: backward-data only");
+    using Cfg = RpCfg<R>;
+    constexpr int TH = Cfg::TH, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, NITEM = Cfg::NITEM, NV = Cfg::NV;
+    constexpr int CT = 16 * MF, CTX = CT + (REM ? 4 : 0);
+    constexpr int WFR = 4 * 16 * 12;                           // floats of one output fragment's weight chunk: [k 4][m 16][ky 3][4]
+    constexpr int WCH = MF * WFR + (REM ? 4 * 4 * 12 : 0);     // + the 4 extra channels [k 4][m 4][ky 3][4]
+
+    extern __shared__ __align__(16) float s_dyn[];             // [2][WCH] weight chunks | ChanFwd[Cin] | ChanBwd[Cout]
+    __shared__ __align__(16) float s_x[2][4 * PLANE];
+    __shared__ float s_bias[CT];
+    __shared__ double s_red[4][CTX][2];
+
+#ifdef RP_PROF
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    RP_T(t_entry);
+#endif
+    const ConvGeom& g = A.g;
+    const int tid = threadIdx.x;
+    const bool producer = tid >= 256;
+    const int t = tid & 255, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int bx, by, k;
+    xcd_decode(blockIdx.x, A.nx, A.ny, A.nz, bx, by, k);
+    const int m0 = by * CT;
+    const int H = g.H, W = g.W, HW = H * W;
+    const int RED = MODE == 0 ? g.Cin : g.Cout;
+    const int MOUT = MODE == 0 ? g.Cout : g.Cin;
+    const int mt = min(CT, MOUT - m0);
+    const bool rem_blk = REM && by == A.ny - 1;
+    const int mtx = mt + (rem_blk ? 4 : 0);
+    const int n_chunks = RED >> 2;
+
+    const float* __restrict__ wk = A.w + (long long)k * A.wstride;
+    float* __restrict__ s_w = s_dyn;
+    ChanFwd* __restrict__ s_ch = reinterpret_cast<ChanFwd*>(s_dyn + 2 * WCH);
+    RpBwd* __restrict__ s_chb = reinterpret_cast<RpBwd*>(s_ch + ((g.Cin + 3) & ~3));
+    const bool fuse_sums = MODE == 1 && A.fbsums != nullptr;
+
+    // per-channel constants, by the consumer waves (the producers go straight to their first global loads)
+    if (!producer) {
+        if (MODE == 0) {
+            for (int c = tid; c < g.Cin; c += 256) s_ch[c] = chan_fwd(A.xin, k, c);
+            if (tid < CT) { const int co = m0 + tid; s_bias[tid] = (co < g.Cout && g.b_off >= 0) ? wk[g.b_off + co] : 0.f; }
+        } else {
+            for (int c = tid; c < g.Cout; c += 256) { const ChanBwd b = chan_bwd(A.gin, k, c); RpBwd r; r.mean = b.mean; r.qc = -b.c1 * b.c3 * b.rstd; r.c1 = b.c1; r.k2 = -b.c1 * b.c2; s_chb[c] = r; }
+            if (fuse_sums) for (int c = tid; c < g.Cin; c += 256) s_ch[c] = chan_fwd(A.xin, k, c);
+        }
+    }
+
+    const int tile_begin = bx * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
+    if (tile_begin >= tile_end) return;
+    const int n_iters = (tile_end - tile_begin) * n_chunks;
+
+    if (producer) {
+        // ======================= producer waves =======================
+#ifndef RP_NOPRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
+        const int pw = wv;                                       // channel of the chunk this wave stages
+        const float* __restrict__ xsrc = MODE == 0 ? A.xin.data + (long long)k * A.xin.sstride : A.gin.ga + (long long)k * A.gin.gstride;
+        const float* __restrict__ ysrc = (MODE == 1 && A.gin.stats) ? A.gin.y + (long long)k * A.gin.ystride : nullptr;
+        const bool xlrelu = (A.xin.act & 1) != 0; const float xslope = A.xin.slope;
+        // The staging loop is kept to a minimum of instructions: its VALU / LDS-write issue competes with the consumers' matrix stream on the
+        // same SIMDs (first version of this kernel: ~600 instructions per 5-quad stage, 0.64 of the matrix peak against 0.76 with the staging
+        // switched off).  Item q = lane + 64 j of the channel's window = quad v of window row iy: goff = element offset of the float4 to load
+        // (always a valid address; the channel base is wave-uniform and goes in as the scalar base of the load), flag (2 bits per item) =
+        // 1 left image border (loaded x[0..3], wanted columns -1..2), 2 right border (loaded x[W-4..W-1], wanted W-1..W+2), 3 = a row
+        // outside the image (MODE 1: zeros); anyf = items of this WAVE with a flagged lane (scalar: interior tiles skip the fix-up code).
+        unsigned goff[NV]; unsigned flags = 0, anyf = 0;
+        float4 xv[NV], yv[MODE == 1 ? NV : 1];
+        auto set_tile = [&](int tile) {
+            const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+            flags = 0; anyf = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int q = min(lane + 64 * j, NITEM - 1), iy = q / Cfg::NQ, v = q - iy * Cfg::NQ;
+                int gy = py0 - 1 + iy, gx = px0 - 1 + 4 * v; unsigned flag = 0;
+                if (MODE == 0) { gy = reflect_idx(gy, H); gy = min(max(gy, 0), H - 1); }
+                else if (gy < 0 || gy >= H) { flag = 3; gy = 0; }
+                if (gx < 0) { if (flag == 0) flag = 1; gx = 0; }
+                else if (gx + 3 >= W) { if (flag == 0) flag = 2; gx = W - 4; }
+                goff[j] = (unsigned)(gy * W + gx);
+                flags |= flag << (2 * j);
+                if (__builtin_amdgcn_ballot_w64(flag != 0) != 0) anyf |= 1u << j;
+            }
+        };
+        auto prefetch = [&](int c0) {
+            const float* __restrict__ xc = xsrc + (long long)(c0 + pw) * HW;       // wave-uniform
+            const float* __restrict__ yc = ysrc ? ysrc + (long long)(c0 + pw) * HW : xc;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+#if defined(RP_DBG_NOLOAD) || defined(RP_DBG_NOPROD)
+                xv[j] = make_float4(1.f, 2.f, 3.f, 4.f); if (MODE == 1) yv[j] = xv[j]; continue;
+#endif
+                const f4u a = *reinterpret_cast<const f4u*>(xc + goff[j]);
+                xv[j] = make_float4(a.x, a.y, a.z, a.w);
+                if (MODE == 1) { if (ysrc) { const f4u b = *reinterpret_cast<const f4u*>(yc + goff[j]); yv[j] = make_float4(b.x, b.y, b.z, b.w); } }
+            }
+        };
+        auto store = [&](int c0, float* __restrict__ dst) {
+#ifdef RP_DBG_NOPROD
+            return;
+#endif
+            const int ch = c0 + pw;
+            ChanFwd kf; RpBwd kb;
+            if (MODE == 0) kf = s_ch[ch]; else kb = s_chb[ch];
+            float* __restrict__ d = dst + pw * PLANE + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float e[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+                // plain fp32 instructions: beside a matrix stream the packed forms (v_pk_fma_f32 ...) cost more issue time than the two
+                // scalar ones they replace (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'; A/B on the three big layers: 2-4 %)
+#ifndef RP_DBG_RAWCOPY
+                if (MODE == 0) {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) { float v = __builtin_fmaf(e[l] - kf.mean, kf.scale, kf.beta); if (xlrelu) v = __builtin_fmaxf(v, v * xslope); e[l] = v; }
+                } else if (ysrc) {
+                    const float yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w};
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) e[l] = __builtin_fmaf(yy[l] - kb.mean, kb.qc, __builtin_fmaf(e[l], kb.c1, kb.k2));
+                }
+#endif
+                if (anyf & (1u << j)) {       // wave-uniform: some lane of this item sits on an image border
+                    const unsigned flag = (flags >> (2 * j)) & 3u;
+                    if (MODE == 0) {
+                        if (flag == 1) { const float e0 = e[0]; e[0] = e[1]; e[3] = e[2]; e[2] = e[1]; e[1] = e0; }      // columns -1..2 <- x[1], x[0], x[1], x[2]
+                        else if (flag == 2) { e[0] = e[3]; e[1] = e[2]; }                                                 // columns W-1, W <- x[W-1], x[W-2]
+                    } else {
+                        if (flag == 1) { e[3] = e[2]; e[2] = e[1]; e[1] = e[0]; e[0] = 0.f; }                             // columns -1..2 <- 0, dy[0], dy[1], dy[2]
+                        else if (flag == 2) { e[0] = e[3]; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }                          // columns W-1.. <- dy[W-1], 0, 0, 0
+                        else if (flag == 3) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+                    }
+                }
+#ifdef RP_DBG_NOXSTORE
+                if (e[0] == 1.2345f)
+#endif
+                if (64 * (j + 1) <= NITEM || lane + 64 * j < NITEM) *reinterpret_cast<float4*>(d + 256 * j) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        };
+        // weight chunk of reduction channels c0..c0+3: global -> registers (one stage ahead) -> LDS [f][k][m][ky][4] (+ extra channels [k][m 4][ky][4]).
+        // One item = one DESTINATION quad (k, m, ky): its three taps are three consecutive floats of the global row [m][c][9] (MODE 1:
+        // [c][m][9], reversed: flipped taps), fetched as one dword-aligned float4 — floats 0..3 of the row for its first tap row, 3..6 for
+        // the second, 5..8 (taps in .y .z .w) for the third, so nothing outside the row is ever read — and stored with one ds_write_b128.  Source offset and LDS offset are fixed per thread.  (First version: aligned float4 of the source
+        // scattered with four exec-masked ds_write_b32 each — 9 % of the kernel's time on the 132 -> 64 layer.)
+        constexpr int WITEMS = CTX * 12;                          // quads per chunk
+        constexpr int WNR = (WITEMS + 255) / 256;
+        const float* __restrict__ wl = wk + g.w_off;
+        f4u wreg[WNR];
+        int wsrc[WNR];               // float offset at chunk 0, -1: zeros (output channel beyond the tensor)
+        short wdst_o[WNR];           // LDS float offset, -1: no such item
+        bool wsh[WNR];               // third tap row of the source: the taps sit in .y .z .w
+#pragma unroll
+        for (int j = 0; j < WNR; ++j) {
+            const int idx = t + 256 * j;
+            wsrc[j] = -1; wdst_o[j] = -1; wsh[j] = false;
+            if (idx < WITEMS) {
+                const int ky = idx % 3, kk = (idx / 3) & 3, m = idx / 12;
+                const int sr = MODE == 0 ? ky : 2 - ky;           // tap row of the source
+                wsh[j] = sr == 2;
+                wdst_o[j] = (short)(m < CT ? (((m >> 4) * 4 + kk) * 16 + (m & 15)) * 12 + ky * 4 : MF * WFR + (kk * 4 + (m - CT)) * 12 + ky * 4);
+                if (m < mtx) wsrc[j] = (MODE == 0 ? ((m0 + m) * g.Cin + kk) * 9 : (kk * g.Cin + m0 + m) * 9) + (sr == 2 ? 5 : 3 * sr);
+            }
+        }
+        const int wstep = MODE == 0 ? 36 : g.Cin * 36;            // floats per 4 reduction channels
+        auto wfetch = [&](int c0) {
+            const float* __restrict__ wc = wl + (long long)(c0 >> 2) * wstep;
+#pragma unroll
+            for (int j = 0; j < WNR; ++j) {
+                wreg[j] = (f4u){0.f, 0.f, 0.f, 0.f};
+                if (wsrc[j] >= 0) wreg[j] = *reinterpret_cast<const f4u*>(wc + wsrc[j]);
+            }
+        };
+        auto wstore = [&](float* __restrict__ wdst) {
+#ifdef RP_DBG_NOWSTORE
+            return;
+#endif
+#pragma unroll
+            for (int j = 0; j < WNR; ++j)
+                if (256 * (j + 1) <= WITEMS || wdst_o[j] >= 0) {
+                    const f4u v = wreg[j];
+                    const float t0 = wsh[j] ? v.y : v.x, t1 = wsh[j] ? v.z : v.y, t2 = wsh[j] ? v.w : v.z;
+                    *reinterpret_cast<float4*>(wdst + wdst_o[j]) = MODE == 0 ? make_float4(t0, t1, t2, 0.f) : make_float4(t2, t1, t0, 0.f);
+                }
+        };
+
+        // running (tile, chunk) of the stage being fetched: two stages ahead of the consumers
+        int ftile = tile_begin, fc = 0;
+        auto advance = [&]() { fc += 4; if (fc >= RED) { fc = 0; ++ftile; return true; } return false; };
+        set_tile(ftile); prefetch(fc); wfetch(fc);
+        __syncthreads();                                  // (S0) channel constants / bias visible
+        store(fc, s_x[0]); wstore(s_w);
+        int sc = 0;                                       // chunk base of the stage held in registers (stored next)
+        if (n_iters > 1) { if (advance()) set_tile(ftile); sc = fc; prefetch(fc); wfetch(fc); }
+        lds_barrier();                                    // (A) chunk 0 published
+        RP_T(p_loop0); RP_ACC(8, p_loop0 - t_entry);
+        for (int it = 0; it < n_iters; ++it) {
+            RP_T(p0);
+            if (it + 1 < n_iters) {
+#ifdef RP_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                RP_T(p1); RP_ACC(9, p1 - p0);                                   // waiting for the prefetched loads
+                store(sc, s_x[(it + 1) & 1]); wstore(s_w + ((it + 1) & 1) * WCH);
+                RP_T(p2); RP_ACC(10, p2 - p1);                                  // transform + LDS writes
+                if (it + 2 < n_iters) { if (advance()) set_tile(ftile); sc = fc; prefetch(fc); wfetch(fc); }
+                RP_T(p3); RP_ACC(11, p3 - p2);                                  // issuing the next loads
+            }
+            RP_T(p4);
+            lds_barrier();
+            RP_T(p5); RP_ACC(12, p5 - p4);                                      // barrier wait
+        }
+        RP_T(p_end); RP_ACC(13, p_end - p_loop0);
+#ifdef RP_PROF
+        if (t == 0) for (int i = 8; i < 14; ++i) atomicAdd(&g_rp_prof[i], prof[i]);
+#endif
+        if ((MODE == 0 && A.out.stats != nullptr) || fuse_sums) __syncthreads();        // (Z)
+    } else {
+        // ======================= consumer waves =======================
+        const bool do_stats = (MODE == 0 && A.out.stats != nullptr) || fuse_sums;
+        if (do_stats) for (int q = lane; q < CTX; q += 64) { s_red[wv][q][0] = 0.0; s_red[wv][q][1] = 0.0; }
+        f32x4 acc[MF][R][4];
+        f32x4 accx[REM ? R : 1][REM ? 4 : 1];
+        const int xb = l4 * PLANE + (wv * R) * PITCH + 4 * l15;          // this lane's six-float window read, row 0 of the wave
+        const int wb = (l4 * 16 + l15) * 12;                             // weights of (k = l4, m = l15)
+        const int wxb = MF * WFR + (l4 * 4 + (lane & 3)) * 12;           // REM: A operand of the 4x4x1 instruction = w[extra channel lane & 3][k = l4]
+        __syncthreads();                                  // (S0)
+        lds_barrier();                                    // (A)
+        RP_T(c_loop0); RP_ACC(0, c_loop0 - t_entry);
+        for (int it = 0; it < n_iters; ++it) {
+            RP_T(c0);
+            const int tile = tile_begin + it / n_chunks, ci = it % n_chunks;
+            const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+            const int row0 = py0 + wv * R;                               // first image row of this wave
+            if (ci == 0) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[f][r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (REM) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accx[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            const float* __restrict__ sx = s_x[it & 1] + xb;
+            const float* __restrict__ sw = s_w + (it & 1) * WCH;
+            // window rows of the wave: R + 2 rows x 6 floats (+ MODE 1: the two column-patched operands, see the header)
+            float b[R + 2][MODE == 1 ? 8 : 6];
+#pragma unroll
+            for (int rr = 0; rr < R + 2; ++rr) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sx + rr * PITCH);
+                const f32x2 hi = *reinterpret_cast<const f32x2*>(sx + rr * PITCH + 4);
+                b[rr][0] = lo.x; b[rr][1] = lo.y; b[rr][2] = lo.z; b[rr][3] = lo.w; b[rr][4] = hi.x; b[rr][5] = hi.y;
+            }
+            if constexpr (MODE == 1) {
+                // column part of the reflection adjoint: image column 1 (phase 1 of lane 0 in the leftmost tile) takes tap kx = 2 from
+                // win[3] + win[1]; column W-2 (phase 2 of lane 15 in the rightmost tile) takes tap kx = 0 from win[2] + win[4]
+                const float ml = (px0 == 0 && l15 == 0) ? 1.f : 0.f, mr = (px0 + 64 == W && l15 == 15) ? 1.f : 0.f;
+#pragma unroll
+                for (int rr = 0; rr < R + 2; ++rr) { b[rr][6] = __builtin_fmaf(ml, b[rr][1], b[rr][3]); b[rr][7] = __builtin_fmaf(mr, b[rr][4], b[rr][2]); }
+            }
+            auto bop = [&](int rr, int j, int kx) -> float {
+                if constexpr (MODE == 1) { if (j == 1 && kx == 2) return b[rr][6]; if (j == 2 && kx == 0) return b[rr][7]; }
+                return b[rr][j + kx];
+            };
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                f32x4 a[MF]; f32x4 ax;
+#pragma unroll
+                for (int f = 0; f < MF; ++f) a[f] = *reinterpret_cast<const f32x4*>(sw + f * WFR + wb + ky * 4);
+                if constexpr (REM) ax = *reinterpret_cast<const f32x4*>(sw + wxb + ky * 4);
+                auto taps = [&](int r, int rr) {          // output row r of the wave x window row rr, the three kx taps, four phases
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float bv = bop(rr, j, kx);
+#pragma unroll
+                            for (int f = 0; f < MF; ++f) acc[f][r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][kx], bv, acc[f][r][j], 0, 0, 0);
+                            if constexpr (REM) { if (rem_blk) accx[r][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax[kx], bv, accx[r][j], 0, 0, 0); }
+                        }
+                };
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    taps(r, r + ky);
+                    if constexpr (MODE == 1) {
+                        // row part of the reflection adjoint: image row 1 also receives tap ky = 2 applied to the window row of its tap 0 (padded
+                        // row -1), image row H-2 tap 0 applied to the window row of its tap 2 (padded row H)
+                        if (ky == 2 && row0 + r == 1) taps(r, r);
+                        if (ky == 0 && row0 + r == H - 2) taps(r, r + 2);
+                    }
+                }
+            }
+
+            RP_T(c1); RP_ACC(1, c1 - c0);                                        // MFMA phase (issue time: the last MFMAs still run)
+#ifdef RP_DBG_NOEPI
+            if (ci == n_chunks - 1 && A.tiles_x < 0) {
+#else
+            if (ci == n_chunks - 1) {
+#endif
+                // ---- epilogue: register q of (f, r, phase 0..3) = channel m0 + 16 f + 4 l4 + q, row row0 + r, pixels px0 + 4 l15 .. +3 ----
+                if constexpr (MODE == 0) {
+                    float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HW;
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int ml = f * 16 + l4 * 4 + q;
+                                const float bi = s_bias[ml];
+                                const float v0 = acc[f][r][0][q] + bi, v1 = acc[f][r][1][q] + bi, v2 = acc[f][r][2][q] + bi, v3 = acc[f][r][3][q] + bi;
+                                if (ml < mt) {
+                                    *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(v0, v1, v2, v3);
+                                    fs[q] += (v0 + v1) + (v2 + v3);
+                                    fq[q] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, fq[q]))));
+                                }
+                            }
+                        if (do_stats) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float a_ = fs[q], b_ = fq[q];
+#pragma unroll
+                                for (int o = 8; o > 0; o >>= 1) { a_ += __shfl_xor(a_, o, 64); b_ += __shfl_xor(b_, o, 64); }
+                                if (l15 == 0) { s_red[wv][f * 16 + l4 * 4 + q][0] += (double)a_; s_red[wv][f * 16 + l4 * 4 + q][1] += (double)b_; }
+                            }
+                        }
+                    }
+                } else {
+                    float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * HW;
+                    const float* __restrict__ xraw = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HW;
+                    const int xact = A.xin.act; const float xslope = A.xin.slope;
+                    auto fold4 = [&](int ml, int r, float (&dd)[4], float& fsum, float& fxs, const float4 y4) {
+                        if (fuse_sums) {
+                            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+                            const ChanFwd cf = s_ch[m0 + ml];
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) {
+                                const float vv = __builtin_fmaf(yy[l] - cf.mean, cf.scale, cf.beta);
+                                if (xact && !(vv > 0.f)) dd[l] *= xslope;
+                                fsum += dd[l]; fxs = __builtin_fmaf(dd[l], (yy[l] - cf.mean) * cf.rstd, fxs);
+                            }
+                        }
+                        *reinterpret_cast<float4*>(o + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                    };
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        // all raw-x float4 of the fragment are requested together
+                        float4 y4[R][4];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y4[r][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (fuse_sums) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int ml = min(f * 16 + l4 * 4 + q, mt - 1);
+                                    y4[r][q] = *reinterpret_cast<const float4*>(xraw + ml * HW + (row0 + r) * W + px0 + 4 * l15);
+                                }
+                        }
+                        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int ml = f * 16 + l4 * 4 + q;
+                                float dd[4] = {acc[f][r][0][q], acc[f][r][1][q], acc[f][r][2][q], acc[f][r][3][q]};
+                                if (ml < mt) fold4(ml, r, dd, fs[q], fq[q], y4[r][q]);
+                            }
+                        if (fuse_sums) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float a_ = fs[q], b_ = fq[q];
+#pragma unroll
+                                for (int o2 = 8; o2 > 0; o2 >>= 1) { a_ += __shfl_xor(a_, o2, 64); b_ += __shfl_xor(b_, o2, 64); }
+                                if (l15 == 0) { s_red[wv][f * 16 + l4 * 4 + q][0] += (double)a_; s_red[wv][f * 16 + l4 * 4 + q][1] += (double)b_; }
+                            }
+                        }
+                    }
+                    if constexpr (REM) {
+                        if (rem_blk) {
+                            // 4x4x1 accumulators: register q of (r, phase j) = extra channel q at pixel 4 l15 + j, this lane's reduction-channel slice
+                            // (k = l4): add the four slices, then lane group l4 == q' folds and stores channel q'
+                            float fs = 0.f, fq = 0.f;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                float dd[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    float mine = 0.f;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        float v = accx[r][j][q]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                                        if (l4 == q) mine = v;
+                                    }
+                                    dd[j] = mine;
+                                }
+                                const int ml = CT + l4;
+                                float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (fuse_sums) y4 = *reinterpret_cast<const float4*>(xraw + ml * HW + (row0 + r) * W + px0 + 4 * l15);
+                                fold4(ml, r, dd, fs, fq, y4);
+                            }
+                            if (fuse_sums) {
+#pragma unroll
+                                for (int o2 = 8; o2 > 0; o2 >>= 1) { fs += __shfl_xor(fs, o2, 64); fq += __shfl_xor(fq, o2, 64); }
+                                if (l15 == 0) { s_red[wv][CT + l4][0] += (double)fs; s_red[wv][CT + l4][1] += (double)fq; }
+                            }
+                        }
+                    }
+                }
+            }
+            RP_T(c2); RP_ACC(2, c2 - c1);                                        // epilogue
+            lds_barrier();
+            RP_T(c3); RP_ACC(3, c3 - c2);                                        // barrier wait
+        }
+        RP_T(c_end); RP_ACC(4, c_end - c_loop0);
+#ifdef RP_PROF
+        if (t == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&g_rp_prof[i], prof[i]); atomicAdd(&g_rp_prof[5], 1ull); atomicAdd(&g_rp_prof[6], (unsigned long long)n_iters); }
+#endif
+        if (do_stats) {
+            __syncthreads();                              // (Z)
+            if (t < CTX * 2) {
+                const int q = t >> 1, which = t & 1;
+                if (q < mtx)
+                    atomicAdd((MODE == 0 ? A.out.stats + ((long long)k * g.Cout + m0 + q) * 2 : A.fbsums + ((long long)k * g.Cin + m0 + q) * 2) + which,
+                              s_red[0][q][which] + s_red[1][q][which] + s_red[2][q][which] + s_red[3][q][which]);
+            }
+        }
+    }
+}
+
+template <int MODE, int MF, int R, bool REM>
+int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
+{
+    using Cfg = RpCfg<R>;
+    const ConvGeom& g = A.g;
+    const int MOUT = MODE == 0 ? g.Cout : g.Cin;
+    constexpr int CT = 16 * MF;
+    if (g.H % Cfg::TH) return -3;
+    if (REM && !((MOUT & 15) == 4 && (MOUT - 4) % CT == 0)) return -3;
+    A.tiles_x = g.W / 64;
+    A.n_tiles = A.tiles_x * (g.H / Cfg::TH);
+    A.tiles_per_block = T;
+    A.nx = (A.n_tiles + T - 1) / T; A.ny = REM ? (MOUT - 4) / CT : (MOUT + CT - 1) / CT; A.nz = n_samples;
+    constexpr int WCH = MF * 4 * 16 * 12 + (REM ? 4 * 4 * 12 : 0);
+    const size_t dyn = sizeof(float) * 2 * WCH + sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(RpBwd) * (size_t)((g.Cout + 3) & ~3);
+    constexpr int MINW = 4;
+    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, MINW>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
+    return (int)hipGetLastError();
+}
+
+// tune code: mf | r << 8 | T << 16 | rem << 12 | MFVI_TUNE_RP
+template <int MODE>
+int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
+{
+    const int mf = tune & 255, r = (tune >> 8) & 15, rem = (tune >> 12) & 1, T = max(1, (tune >> 16) & 255);
+#define RP_GO(MF_, R_) if (mf == MF_ && r == R_) { if constexpr (MODE == 1) { if (rem) return launch_rp<MODE, MF_, R_, true>(A, T, n_samples, st); } if (rem) return -3; return launch_rp<MODE, MF_, R_, false>(A, T, n_samples, st); }
+    RP_GO(1, 1) RP_GO(1, 2) RP_GO(1, 4) RP_GO(2, 1) RP_GO(2, 2) RP_GO(4, 1)
+#undef RP_GO
+    return -3;
+}
+
+}  // namespace
+
+// Returns -2 when the shape is not served by the row-phase kernels, -3 when the tiling is not valid for it.
+int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st)
+{
+    if (g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3) || (g.Cin & 3) || (g.w_off & 3) || g.Cin > MFVI_MAX_C) return -2;
+    if ((in.sstride & 3) || ((uintptr_t)in.data & 15) || (out.sstride & 3) || ((uintptr_t)out.data & 15)) return -2;
+    if (in.act & MFVI_ACT_SQUARE) return -2;                                          // variance convolution of the LRT layers: round-2 kernels
+    if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 29)) return -2;          // 32-bit element offsets per sample, two flag bits
+    RpArgs A{};
+    A.xin = in; A.g = g; A.w = w; A.wstride = wstride; A.out = out;
+    return dispatch_rp<0>(A, tune & ~(1 << 12), n_samples, st);      // the remainder bit only concerns backward-data
+}
+
+int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse)
+{
+    if (g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3) || g.H < 4 || (g.Cin & 3) || (g.Cout & 3) || (g.w_off & 3) || g.Cout > MFVI_MAX_C || g.Cin > MFVI_MAX_C) return -2;
+    if (!fuse.ga || (fuse.ga_sstride & 3) || ((uintptr_t)fuse.ga & 15)) return -2;
+    if ((gy.gstride & 3) || ((uintptr_t)gy.ga & 15) || (gy.stats && ((gy.ystride & 3) || ((uintptr_t)gy.y & 15)))) return -2;
+    if (fuse.bsums && ((fuse.x.sstride & 3) || ((uintptr_t)fuse.x.data & 15))) return -2;
+    if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 29)) return -2;
+    RpArgs A{};
+    A.xin = fuse.x; A.gin = gy; A.g = g; A.w = w; A.wstride = wstride;
+    A.fga = fuse.ga; A.fga_sstride = fuse.ga_sstride; A.fbsums = fuse.bsums;
+    return dispatch_rp<1>(A, tune, n_samples, st);
+}
+
+// Heuristic tiling when the plan holds none (mfvi_plan_autotune times the candidates on the real tensors).  MFVI_RP=0 keeps the round-2 kernels
+// (A/B runs and the cross-check tests); MFVI_TUNE_RP=mf,r,T[,rem] forces one tiling for experiments.
+int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
+{
+    static const int on = [] { const char* e = getenv("MFVI_RP"); return !(e && e[0] == '0'); }();
+    if (!on || g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3)) return 0;
+    static const int forced = [] { int mf = 0, r = 0, T = 1, rem = 0; const char* e = getenv("MFVI_TUNE_RP"); if (e) sscanf(e, "%d,%d,%d,%d", &mf, &r, &T, &rem); return mf > 0 ? (mf | r << 8 | (rem & 1) << 12 | T << 16) : 0; }();
+    if (forced) return forced | MFVI_TUNE_RP;
+    const int MOUT = mode == 0 ? g.Cout : g.Cin;
+    const int rem = (mode == 1 && (MOUT & 15) == 4) ? 1 : 0;
+    const int mo = MOUT - 4 * rem;
+    if (mo < 16) return 0;
+    const int mf = (mo % 32 == 0) ? 2 : 1;
+    const long long units = (long long)(g.W / 64) * (g.H / 4) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles
+    int r = 1;
+    if (!(rem && mf == 2) && (g.H & 7) == 0 && units / 2 >= 512) r = 2;
+    return mf | r << 8 | rem << 12 | 1 << 16 | MFVI_TUNE_RP;
+}
+
+#ifdef RP_PROF
+extern "C" int mfvi_debug_rp_prof(unsigned long long* out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rp_prof), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) { unsigned long long z[16] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_rp_prof), z, sizeof(z)); }
+    return (int)e;
+}
+#endif
