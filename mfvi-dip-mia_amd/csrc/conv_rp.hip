@@ -17,9 +17,13 @@
 //
 // MODE 0 forward:       m = cout, k = cin; window = reflection-padded view(x) (deferred BN + LeakyReLU applied by the staging waves)
 // MODE 1 backward-data: m = cin,  k = cout, flipped taps; window = zero-padded dy (BN-backward formed on load); the gradient is formed on the
-//         UN-padded input domain with the adjoint of the reflection padding folded in (rows: two extra tap rows of MFMAs for image rows 1 and
-//         H-2, wave-uniform; columns: one fma on the pixel operand of image columns 1 and W-2), and the epilogue is the fold of the input
-//         tensor: LeakyReLU'(view(x)), BN-backward sums, ga written once (what finalize_dx did as a separate launch in round 1).
+//         UN-padded input domain with the adjoint of the reflection padding folded in, and the epilogue is the fold of the input tensor:
+//         LeakyReLU'(view(x)), BN-backward sums, ga written once (what finalize_dx did as a separate launch in round 1).
+//         Rows:    dx[1] = w'(0) * dy[0] + w'(1) * dy[1] + w'(2) * (dy[2] + dy[0])   (padded row -1 folds onto row 1), likewise
+//                  dx[H-2] = w'(0) * (dy[H-3] + dy[H-1]) + ...: the staging wave of a channel adds the two rows in LDS into a spare window
+//                  row and the one wave that owns image row 1 (H-2) reads that row in place of dy[2] (dy[H-3]) — a different LDS row
+//                  offset, no extra MFMA, no branch in the matrix stream (rows 1 / H-2 are the last / first row of their wave for R <= 2).
+//         Columns: one fma on the pixel operand of image columns 1 and W-2 (masks are zero elsewhere).
 //   REM: the 4 + 16n channels of the skip() concats — the block that owns the last fragments carries the 4 extra output channels on
 //         v_mfma_f32_4x4x1_16B_f32 against the pixel fragments already in registers (as conv_mfma.hip's REM).
 // Block: 512 threads; waves 0-3 issue MFMAs (wave w owns rows w R .. w R + R - 1 of a (4 R) x 64 tile), waves 4-7 stage the next 4-channel
@@ -60,28 +64,36 @@ __device__ __forceinline__ unsigned long long rp_now() { unsigned long long t; a
 // (chan_bwd's  c1 * (ga - c2 - xhat * c3)  with the products of the channel constants formed once per block)
 struct RpBwd { float mean, qc, c1, k2; };
 
-template <int R>
+template <int R, int MODE>
 struct RpCfg {
     static constexpr int TH = 4 * R, WROWS = TH + 2, NQ = 17, PITCH = 4 * NQ;       // 66 window columns -> 17 quads
-    static constexpr int PLANE = (WROWS * PITCH + 63) / 64 * 64;                    // == 0 (mod 64): the 16-lane groups of a ds_read_b128 hit 64 distinct banks
+    // MODE 1: two extra rows per channel plane hold the row part of the reflection adjoint (S1 = dy[2] + dy[0] for image row 1,
+    // S2 = dy[H-3] + dy[H-1] for image row H-2; see the kernel's header)
+    static constexpr int PROWS = WROWS + (MODE == 1 ? 2 : 0);
+    static constexpr int PLANE = (PROWS * PITCH + 63) / 64 * 64;                    // == 0 (mod 64): the 16-lane groups of a ds_read_b128 hit 64 distinct banks
     static constexpr int NITEM = WROWS * NQ, NV = (NITEM + 63) / 64;
 };
 
 // MINW: minimum waves per SIMD the register allocation must allow (4 = 128 VGPRs = two 512-thread blocks per CU)
-template <int MODE, int MF, int R, bool REM, int MINW>
+// KS: 4-channel k-steps per stage (one barrier per stage: a stage boundary costs ~800 cycles of matrix time, see NOTES)
+template <int MODE, int MF, int R, bool REM, int KS, int MINW>
 __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
 {
     static_assert(!REM || MODE == 1, "remainder channels: backward-data only");
-    using Cfg = RpCfg<R>;
+    static_assert(MODE == 0 || R <= 2, "backward-data: image rows 1 / H-2 must be the last / first row of their wave");
+    using Cfg = RpCfg<R, MODE>;
     constexpr int TH = Cfg::TH, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, NITEM = Cfg::NITEM, NV = Cfg::NV;
     constexpr int CT = 16 * MF, CTX = CT + (REM ? 4 : 0);
     constexpr int WFR = 4 * 16 * 12;                           // floats of one output fragment's weight chunk: [k 4][m 16][ky 3][4]
-    constexpr int WCH = MF * WFR + (REM ? 4 * 4 * 12 : 0);     // + the 4 extra channels [k 4][m 4][ky 3][4]
+    constexpr int WCH1 = MF * WFR + (REM ? 4 * 4 * 12 : 0);    // + the 4 extra channels [k 4][m 4][ky 3][4]
+    constexpr int WCH = KS * WCH1;                             // one stage
 
     extern __shared__ __align__(16) float s_dyn[];             // [2][WCH] weight chunks | ChanFwd[Cin] | ChanBwd[Cout]
-    __shared__ __align__(16) float s_x[2][4 * PLANE];
+    __shared__ __align__(16) float s_x[2][KS * 4 * PLANE];
     __shared__ float s_bias[CT];
-    __shared__ double s_red[4][CTX][2];
+    __shared__ double s_red[MODE == 0 ? 4 : 1][MODE == 0 ? CTX : 1][2];
+    constexpr int OP = TH * 64;                                 // channel pitch of s_out
+    __shared__ __align__(16) float s_out[MODE == 1 ? CTX * OP : 4];      // MODE 1: a finished tile on its way from the consumers to the fold
 
 #ifdef RP_PROF
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
     const int mt = min(CT, MOUT - m0);
     const bool rem_blk = REM && by == A.ny - 1;
     const int mtx = mt + (rem_blk ? 4 : 0);
-    const int n_chunks = RED >> 2;
+    const int n_chunks = RED / (4 * KS);                        // stages per tile (launcher: RED % (4 KS) == 0)
 
     const float* __restrict__ wk = A.w + (long long)k * A.wstride;
     float* __restrict__ s_w = s_dyn;
@@ -141,10 +153,12 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         // 1 left image border (loaded x[0..3], wanted columns -1..2), 2 right border (loaded x[W-4..W-1], wanted W-1..W+2), 3 = a row
         // outside the image (MODE 1: zeros); anyf = items of this WAVE with a flagged lane (scalar: interior tiles skip the fix-up code).
         unsigned goff[NV]; unsigned flags = 0, anyf = 0;
-        float4 xv[NV], yv[MODE == 1 ? NV : 1];
+        bool sp1 = false, sp2 = false;      // MODE 1: the tile of the stage in registers holds image row 1 / H-2
+        float4 xv[KS][NV], yv[MODE == 1 ? KS : 1][MODE == 1 ? NV : 1];
         auto set_tile = [&](int tile) {
             const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
             flags = 0; anyf = 0;
+            sp1 = MODE == 1 && py0 == 0; sp2 = MODE == 1 && py0 + TH == H;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int q = min(lane + 64 * j, NITEM - 1), iy = q / Cfg::NQ, v = q - iy * Cfg::NQ;
@@ -159,56 +173,74 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             }
         };
         auto prefetch = [&](int c0) {
-            const float* __restrict__ xc = xsrc + (long long)(c0 + pw) * HW;       // wave-uniform
-            const float* __restrict__ yc = ysrc ? ysrc + (long long)(c0 + pw) * HW : xc;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const float* __restrict__ xc = xsrc + (long long)(c0 + 4 * s_ + pw) * HW;       // wave-uniform
+                const float* __restrict__ yc = ysrc ? ysrc + (long long)(c0 + 4 * s_ + pw) * HW : xc;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
 #if defined(RP_DBG_NOLOAD) || defined(RP_DBG_NOPROD)
-                xv[j] = make_float4(1.f, 2.f, 3.f, 4.f); if (MODE == 1) yv[j] = xv[j]; continue;
+                    xv[s_][j] = make_float4(1.f, 2.f, 3.f, 4.f); if (MODE == 1) yv[s_][j] = xv[s_][j]; continue;
 #endif
-                const f4u a = *reinterpret_cast<const f4u*>(xc + goff[j]);
-                xv[j] = make_float4(a.x, a.y, a.z, a.w);
-                if (MODE == 1) { if (ysrc) { const f4u b = *reinterpret_cast<const f4u*>(yc + goff[j]); yv[j] = make_float4(b.x, b.y, b.z, b.w); } }
+                    const f4u a = *reinterpret_cast<const f4u*>(xc + goff[j]);
+                    xv[s_][j] = make_float4(a.x, a.y, a.z, a.w);
+                    if (MODE == 1) { if (ysrc) { const f4u b = *reinterpret_cast<const f4u*>(yc + goff[j]); yv[s_][j] = make_float4(b.x, b.y, b.z, b.w); } }
+                }
             }
         };
         auto store = [&](int c0, float* __restrict__ dst) {
 #ifdef RP_DBG_NOPROD
             return;
 #endif
-            const int ch = c0 + pw;
-            ChanFwd kf; RpBwd kb;
-            if (MODE == 0) kf = s_ch[ch]; else kb = s_chb[ch];
-            float* __restrict__ d = dst + pw * PLANE + 4 * lane;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                float e[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-                // plain fp32 instructions: beside a matrix stream the packed forms (v_pk_fma_f32 ...) cost more issue time than the two
-                // scalar ones they replace (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'; A/B on the three big layers: 2-4 %)
-#ifndef RP_DBG_RAWCOPY
-                if (MODE == 0) {
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) { float v = __builtin_fmaf(e[l] - kf.mean, kf.scale, kf.beta); if (xlrelu) v = __builtin_fmaxf(v, v * xslope); e[l] = v; }
-                } else if (ysrc) {
-                    const float yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w};
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) e[l] = __builtin_fmaf(yy[l] - kb.mean, kb.qc, __builtin_fmaf(e[l], kb.c1, kb.k2));
-                }
-#endif
-                if (anyf & (1u << j)) {       // wave-uniform: some lane of this item sits on an image border
-                    const unsigned flag = (flags >> (2 * j)) & 3u;
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const int ch = c0 + 4 * s_ + pw;
+                ChanFwd kf; RpBwd kb;
+                if (MODE == 0) kf = s_ch[ch]; else kb = s_chb[ch];
+                float* __restrict__ d = dst + (4 * s_ + pw) * PLANE + 4 * lane;
+    #pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    float e[4] = {xv[s_][j].x, xv[s_][j].y, xv[s_][j].z, xv[s_][j].w};
+                    // plain fp32 instructions: beside a matrix stream the packed forms (v_pk_fma_f32 ...) cost more issue time than the two
+                    // scalar ones they replace (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'; A/B on the three big layers: 2-4 %)
+    #ifndef RP_DBG_RAWCOPY
                     if (MODE == 0) {
-                        if (flag == 1) { const float e0 = e[0]; e[0] = e[1]; e[3] = e[2]; e[2] = e[1]; e[1] = e0; }      // columns -1..2 <- x[1], x[0], x[1], x[2]
-                        else if (flag == 2) { e[0] = e[3]; e[1] = e[2]; }                                                 // columns W-1, W <- x[W-1], x[W-2]
-                    } else {
-                        if (flag == 1) { e[3] = e[2]; e[2] = e[1]; e[1] = e[0]; e[0] = 0.f; }                             // columns -1..2 <- 0, dy[0], dy[1], dy[2]
-                        else if (flag == 2) { e[0] = e[3]; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }                          // columns W-1.. <- dy[W-1], 0, 0, 0
-                        else if (flag == 3) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+    #pragma unroll
+                        for (int l = 0; l < 4; ++l) { float v = __builtin_fmaf(e[l] - kf.mean, kf.scale, kf.beta); if (xlrelu) v = __builtin_fmaxf(v, v * xslope); e[l] = v; }
+                    } else if (ysrc) {
+                        const float yy[4] = {yv[s_][j].x, yv[s_][j].y, yv[s_][j].z, yv[s_][j].w};
+    #pragma unroll
+                        for (int l = 0; l < 4; ++l) e[l] = __builtin_fmaf(yy[l] - kb.mean, kb.qc, __builtin_fmaf(e[l], kb.c1, kb.k2));
+                    }
+    #endif
+                    if (anyf & (1u << j)) {       // wave-uniform: some lane of this item sits on an image border
+                        const unsigned flag = (flags >> (2 * j)) & 3u;
+                        if (MODE == 0) {
+                            if (flag == 1) { const float e0 = e[0]; e[0] = e[1]; e[3] = e[2]; e[2] = e[1]; e[1] = e0; }      // columns -1..2 <- x[1], x[0], x[1], x[2]
+                            else if (flag == 2) { e[0] = e[3]; e[1] = e[2]; }                                                 // columns W-1, W <- x[W-1], x[W-2]
+                        } else {
+                            if (flag == 1) { e[3] = e[2]; e[2] = e[1]; e[1] = e[0]; e[0] = 0.f; }                             // columns -1..2 <- 0, dy[0], dy[1], dy[2]
+                            else if (flag == 2) { e[0] = e[3]; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }                          // columns W-1.. <- dy[W-1], 0, 0, 0
+                            else if (flag == 3) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+                        }
+                    }
+    #ifdef RP_DBG_NOXSTORE
+                    if (e[0] == 1.2345f)
+    #endif
+                    if (64 * (j + 1) <= NITEM || lane + 64 * j < NITEM) *reinterpret_cast<float4*>(d + 256 * j) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+                if constexpr (MODE == 1) {
+                    // row part of the reflection adjoint (header): window row iy = image row py0 - 1 + iy.  The wave's own ds_writes above are
+                    // ordered before these reads (one wave's LDS operations complete in order).
+                    if (sp1 && lane < Cfg::NQ) {        // tile row 0: S1 = dy[2] + dy[0] = window rows 3 + 1
+                        const float4 u = *reinterpret_cast<const float4*>(d + 3 * PITCH), v = *reinterpret_cast<const float4*>(d + 1 * PITCH);
+                        *reinterpret_cast<float4*>(d + Cfg::WROWS * PITCH) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+                    }
+                    if (sp2 && lane < Cfg::NQ) {        // last tile row: S2 = dy[H-3] + dy[H-1] = window rows TH - 2, TH
+                        const float4 u = *reinterpret_cast<const float4*>(d + (TH - 2) * PITCH), v = *reinterpret_cast<const float4*>(d + TH * PITCH);
+                        *reinterpret_cast<float4*>(d + (Cfg::WROWS + 1) * PITCH) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
                     }
                 }
-#ifdef RP_DBG_NOXSTORE
-                if (e[0] == 1.2345f)
-#endif
-                if (64 * (j + 1) <= NITEM || lane + 64 * j < NITEM) *reinterpret_cast<float4*>(d + 256 * j) = make_float4(e[0], e[1], e[2], e[3]);
             }
         };
         // weight chunk of reduction channels c0..c0+3: global -> registers (one stage ahead) -> LDS [f][k][m][ky][4] (+ extra channels [k][m 4][ky][4]).
@@ -219,7 +251,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         constexpr int WITEMS = CTX * 12;                          // quads per chunk
         constexpr int WNR = (WITEMS + 255) / 256;
         const float* __restrict__ wl = wk + g.w_off;
-        f4u wreg[WNR];
+        f4u wreg[KS][WNR];
         int wsrc[WNR];               // float offset at chunk 0, -1: zeros (output channel beyond the tensor)
         short wdst_o[WNR];           // LDS float offset, -1: no such item
         bool wsh[WNR];               // third tap row of the source: the taps sit in .y .z .w
@@ -237,11 +269,14 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         }
         const int wstep = MODE == 0 ? 36 : g.Cin * 36;            // floats per 4 reduction channels
         auto wfetch = [&](int c0) {
-            const float* __restrict__ wc = wl + (long long)(c0 >> 2) * wstep;
 #pragma unroll
-            for (int j = 0; j < WNR; ++j) {
-                wreg[j] = (f4u){0.f, 0.f, 0.f, 0.f};
-                if (wsrc[j] >= 0) wreg[j] = *reinterpret_cast<const f4u*>(wc + wsrc[j]);
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const float* __restrict__ wc = wl + (long long)((c0 >> 2) + s_) * wstep;
+#pragma unroll
+                for (int j = 0; j < WNR; ++j) {
+                    wreg[s_][j] = (f4u){0.f, 0.f, 0.f, 0.f};
+                    if (wsrc[j] >= 0) wreg[s_][j] = *reinterpret_cast<const f4u*>(wc + wsrc[j]);
+                }
             }
         };
         auto wstore = [&](float* __restrict__ wdst) {
@@ -249,17 +284,81 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             return;
 #endif
 #pragma unroll
-            for (int j = 0; j < WNR; ++j)
-                if (256 * (j + 1) <= WITEMS || wdst_o[j] >= 0) {
-                    const f4u v = wreg[j];
-                    const float t0 = wsh[j] ? v.y : v.x, t1 = wsh[j] ? v.z : v.y, t2 = wsh[j] ? v.w : v.z;
-                    *reinterpret_cast<float4*>(wdst + wdst_o[j]) = MODE == 0 ? make_float4(t0, t1, t2, 0.f) : make_float4(t2, t1, t0, 0.f);
+            for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                for (int j = 0; j < WNR; ++j)
+                    if (256 * (j + 1) <= WITEMS || wdst_o[j] >= 0) {
+                        const f4u v = wreg[s_][j];
+                        const float t0 = wsh[j] ? v.y : v.x, t1 = wsh[j] ? v.z : v.y, t2 = wsh[j] ? v.w : v.z;
+                        *reinterpret_cast<float4*>(wdst + s_ * WCH1 + wdst_o[j]) = MODE == 0 ? make_float4(t0, t1, t2, 0.f) : make_float4(t2, t1, t0, 0.f);
+                    }
+        };
+
+        // ---- MODE 1: the fold of a dumped tile by the staging waves (idle for most of a stage otherwise).  Item idx = t + 256 j of
+        //      [channel][tile row][float4 column]: the channel of (wave, j) is wave-uniform (TH * 16 >= 64 items per channel), so its BN
+        //      constants are scalar and its BN-backward partial sums live in two registers per j for the whole block.  FP parts (items
+        //      j == part mod FP), one per stage 0 .. FP-1 of the NEXT tile (FP <= n_chunks - 1: all parts are done before the consumers'
+        //      next dump, which follows the MFMAs of that tile's last stage); a part's raw-x loads fly while the stage is staged.
+        constexpr int NIT = MODE == 1 ? (CTX * TH * 16) / 256 : 1;
+        static_assert(MODE == 0 || (CTX * TH * 16) % 256 == 0, "fold items");
+        constexpr int FP = 3;                                    // parts when a tile has >= 4 stages; 2 or 3 stages: the whole fold rides on stage 0 (part -1)
+        float fsum[NIT], fxs[NIT]; float4 fxr[MODE == 1 ? (NIT + FP - 1) / FP : 1];
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) { fsum[j] = 0.f; fxs[j] = 0.f; }
+        auto fold_fetch = [&](int tile, auto part_c) {
+            constexpr int part = decltype(part_c)::value;
+            if constexpr (MODE == 1) {
+                if (!fuse_sums) return;
+                const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+                const float* __restrict__ xq = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HW + py0 * W + px0;
+                int tl = t; asm volatile("" : "+v"(tl));       // the items' index arithmetic is recomputed here, not hoisted over the stage loop (27 registers)
+#pragma unroll
+                for (int j = part; j < NIT; j += FP) {
+                    const int idx = tl + 256 * j, ch = idx / (TH * 16), rw = (idx >> 4) % TH, v = idx & 15;
+                    fxr[j / FP] = ch < mtx ? *reinterpret_cast<const float4*>(xq + ch * HW + rw * W + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+            }
+        };
+        auto fold_do = [&](int tile, auto part_c) {
+            constexpr int part = decltype(part_c)::value;
+            if constexpr (MODE == 1) {
+                const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+                float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * HW + py0 * W + px0;
+                const int xact = A.xin.act; const float xslope = A.xin.slope;
+                int tl = t; asm volatile("" : "+v"(tl));
+#pragma unroll
+                for (int j = part; j < NIT; j += FP) {
+                    const int idx = tl + 256 * j, ch = idx / (TH * 16), rw = (idx >> 4) % TH, v = idx & 15;
+                    if (ch < mtx) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(&s_out[ch * OP + rw * 64 + 4 * v]);
+                        float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                        if (fuse_sums) {
+                            // sums of ga and ga * (x - mean); the factor rstd of x-hat is applied once per block.  Views without an
+                            // activation (the concat tensors: BatchNorm only) skip the LeakyReLU' part: 3 operations per element.
+                            const float4 y4_ = fxr[j / FP]; const float yy[4] = {y4_.x, y4_.y, y4_.z, y4_.w};
+                            const ChanFwd cf = s_ch[m0 + ch];
+                            if (xact) {
+#pragma unroll
+                                for (int l = 0; l < 4; ++l) {
+                                    const float ym = yy[l] - cf.mean;
+                                    const float vv = __builtin_fmaf(ym, cf.scale, cf.beta);
+                                    dd[l] *= (vv > 0.f) ? 1.f : xslope;
+                                    fsum[j] += dd[l]; fxs[j] = __builtin_fmaf(dd[l], ym, fxs[j]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int l = 0; l < 4; ++l) { fsum[j] += dd[l]; fxs[j] = __builtin_fmaf(dd[l], yy[l] - cf.mean, fxs[j]); }
+                            }
+                        }
+                        *reinterpret_cast<float4*>(o + ch * HW + rw * W + 4 * v) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                    }
+                }
+            }
         };
 
         // running (tile, chunk) of the stage being fetched: two stages ahead of the consumers
         int ftile = tile_begin, fc = 0;
-        auto advance = [&]() { fc += 4; if (fc >= RED) { fc = 0; ++ftile; return true; } return false; };
+        auto advance = [&]() { fc += 4 * KS; if (fc >= RED) { fc = 0; ++ftile; return true; } return false; };
         set_tile(ftile); prefetch(fc); wfetch(fc);
         __syncthreads();                                  // (S0) channel constants / bias visible
         store(fc, s_x[0]); wstore(s_w);
@@ -267,8 +366,14 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         if (n_iters > 1) { if (advance()) set_tile(ftile); sc = fc; prefetch(fc); wfetch(fc); }
         lds_barrier();                                    // (A) chunk 0 published
         RP_T(p_loop0); RP_ACC(8, p_loop0 - t_entry);
+        int fci = 0, fdt = tile_begin - 1;                // stage index inside the consumers' current tile; tile whose dump is being folded
         for (int it = 0; it < n_iters; ++it) {
             RP_T(p0);
+            // a part's raw-x loads are issued at the head of its stage and fly while the stage is staged.  (Issuing them one stage ahead —
+            // they do not depend on the dump — was built and measured: 0 ... -5 %, NOTES.)
+            constexpr std::integral_constant<int, 0> p0c{}; constexpr std::integral_constant<int, 1> p1c{}; constexpr std::integral_constant<int, 2> p2c{};
+            const bool fold_now = MODE == 1 && fdt >= tile_begin && fci < FP;
+            if (fold_now) { if (fci == 0) fold_fetch(fdt, p0c); else if (fci == 1) fold_fetch(fdt, p1c); else fold_fetch(fdt, p2c); }
             if (it + 1 < n_iters) {
 #ifdef RP_PROF
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -279,189 +384,168 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                 if (it + 2 < n_iters) { if (advance()) set_tile(ftile); sc = fc; prefetch(fc); wfetch(fc); }
                 RP_T(p3); RP_ACC(11, p3 - p2);                                  // issuing the next loads
             }
+            if (fold_now) { if (fci == 0) fold_do(fdt, p0c); else if (fci == 1) fold_do(fdt, p1c); else fold_do(fdt, p2c); }
             RP_T(p4);
             lds_barrier();
             RP_T(p5); RP_ACC(12, p5 - p4);                                      // barrier wait
+            if (++fci == n_chunks) { fci = 0; ++fdt; }
+        }
+        if constexpr (MODE == 1) {      // the block's last tile, then this thread's BN-backward partials (channel of (wave, j): wave-uniform)
+            constexpr std::integral_constant<int, 0> p0c{}; constexpr std::integral_constant<int, 1> p1c{}; constexpr std::integral_constant<int, 2> p2c{};
+            fold_fetch(tile_end - 1, p0c); fold_do(tile_end - 1, p0c); fold_fetch(tile_end - 1, p1c); fold_do(tile_end - 1, p1c); fold_fetch(tile_end - 1, p2c); fold_do(tile_end - 1, p2c);
+            if (fuse_sums) {
+#pragma unroll
+                for (int j = 0; j < NIT; ++j) {
+                    const int ch = (t + 256 * j) / (TH * 16);
+                    const float a_ = wave_sum(fsum[j]), b_ = wave_sum(fxs[j]) * s_ch[m0 + min(ch, mtx - 1)].rstd;
+                    if (lane == 0 && ch < mtx) {
+                        double* dst = A.fbsums + ((long long)k * g.Cin + m0 + ch) * 2;
+                        atomicAdd(dst, (double)a_); atomicAdd(dst + 1, (double)b_);
+                    }
+                }
+            }
         }
         RP_T(p_end); RP_ACC(13, p_end - p_loop0);
 #ifdef RP_PROF
         if (t == 0) for (int i = 8; i < 14; ++i) atomicAdd(&g_rp_prof[i], prof[i]);
 #endif
-        if ((MODE == 0 && A.out.stats != nullptr) || fuse_sums) __syncthreads();        // (Z)
+        if (MODE == 0 && A.out.stats != nullptr) __syncthreads();        // (Z)
     } else {
         // ======================= consumer waves =======================
-        const bool do_stats = (MODE == 0 && A.out.stats != nullptr) || fuse_sums;
+        const bool do_stats = MODE == 0 && A.out.stats != nullptr;
         if (do_stats) for (int q = lane; q < CTX; q += 64) { s_red[wv][q][0] = 0.0; s_red[wv][q][1] = 0.0; }
-        f32x4 acc[MF][R][4];
-        f32x4 accx[REM ? R : 1][REM ? 4 : 1];
         const int xb = l4 * PLANE + (wv * R) * PITCH + 4 * l15;          // this lane's six-float window read, row 0 of the wave
         const int wb = (l4 * 16 + l15) * 12;                             // weights of (k = l4, m = l15)
         const int wxb = MF * WFR + (l4 * 4 + (lane & 3)) * 12;           // REM: A operand of the 4x4x1 instruction = w[extra channel lane & 3][k = l4]
         __syncthreads();                                  // (S0)
         lds_barrier();                                    // (A)
-        RP_T(c_loop0); RP_ACC(0, c_loop0 - t_entry);
-        for (int it = 0; it < n_iters; ++it) {
-            RP_T(c0);
-            const int tile = tile_begin + it / n_chunks, ci = it % n_chunks;
-            const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
-            const int row0 = py0 + wv * R;                               // first image row of this wave
-            if (ci == 0) {
-#pragma unroll
-                for (int f = 0; f < MF; ++f)
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[f][r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (REM) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) accx[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            const float* __restrict__ sx = s_x[it & 1] + xb;
-            const float* __restrict__ sw = s_w + (it & 1) * WCH;
-            // window rows of the wave: R + 2 rows x 6 floats (+ MODE 1: the two column-patched operands, see the header)
-            float b[R + 2][MODE == 1 ? 8 : 6];
-#pragma unroll
-            for (int rr = 0; rr < R + 2; ++rr) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(sx + rr * PITCH);
-                const f32x2 hi = *reinterpret_cast<const f32x2*>(sx + rr * PITCH + 4);
-                b[rr][0] = lo.x; b[rr][1] = lo.y; b[rr][2] = lo.z; b[rr][3] = lo.w; b[rr][4] = hi.x; b[rr][5] = hi.y;
-            }
-            if constexpr (MODE == 1) {
-                // column part of the reflection adjoint: image column 1 (phase 1 of lane 0 in the leftmost tile) takes tap kx = 2 from
-                // win[3] + win[1]; column W-2 (phase 2 of lane 15 in the rightmost tile) takes tap kx = 0 from win[2] + win[4]
-                const float ml = (px0 == 0 && l15 == 0) ? 1.f : 0.f, mr = (px0 + 64 == W && l15 == 15) ? 1.f : 0.f;
-#pragma unroll
-                for (int rr = 0; rr < R + 2; ++rr) { b[rr][6] = __builtin_fmaf(ml, b[rr][1], b[rr][3]); b[rr][7] = __builtin_fmaf(mr, b[rr][4], b[rr][2]); }
-            }
-            auto bop = [&](int rr, int j, int kx) -> float {
-                if constexpr (MODE == 1) { if (j == 1 && kx == 2) return b[rr][6]; if (j == 2 && kx == 0) return b[rr][7]; }
-                return b[rr][j + kx];
-            };
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                f32x4 a[MF]; f32x4 ax;
-#pragma unroll
-                for (int f = 0; f < MF; ++f) a[f] = *reinterpret_cast<const f32x4*>(sw + f * WFR + wb + ky * 4);
-                if constexpr (REM) ax = *reinterpret_cast<const f32x4*>(sw + wxb + ky * 4);
-                auto taps = [&](int r, int rr) {          // output row r of the wave x window row rr, the three kx taps, four phases
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float bv = bop(rr, j, kx);
-#pragma unroll
-                            for (int f = 0; f < MF; ++f) acc[f][r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][kx], bv, acc[f][r][j], 0, 0, 0);
-                            if constexpr (REM) { if (rem_blk) accx[r][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax[kx], bv, accx[r][j], 0, 0, 0); }
-                        }
-                };
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    taps(r, r + ky);
-                    if constexpr (MODE == 1) {
-                        // row part of the reflection adjoint: image row 1 also receives tap ky = 2 applied to the window row of its tap 0 (padded
-                        // row -1), image row H-2 tap 0 applied to the window row of its tap 2 (padded row H)
-                        if (ky == 2 && row0 + r == 1) taps(r, r);
-                        if (ky == 0 && row0 + r == H - 2) taps(r, r + 2);
+        // the whole tile loop exists twice in a REM kernel: with the 4 extra channels (the block that owns the layer's last fragments) and
+        // without them — one wave-uniform branch per block instead of conditions in the matrix stream
+        auto consume = [&](auto remb_c) {
+            constexpr bool REMB = decltype(remb_c)::value;
+            f32x4 acc[MF][R][4];
+            f32x4 accx[REMB ? R : 1][REMB ? 4 : 1];
+            RP_T(c_loop0); RP_ACC(0, c_loop0 - t_entry);
+            for (int it = 0; it < n_iters; ++it) {
+                RP_T(c0);
+                const int tile = tile_begin + it / n_chunks, ci = it % n_chunks;
+                const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+                const int row0 = py0 + wv * R;                               // first image row of this wave
+                if (ci == 0) {
+    #pragma unroll
+                    for (int f = 0; f < MF; ++f)
+    #pragma unroll
+                        for (int r = 0; r < R; ++r)
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[f][r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (REMB) {
+    #pragma unroll
+                        for (int r = 0; r < R; ++r)
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) accx[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                 }
-            }
+                const float* __restrict__ sx0 = s_x[it & 1] + xb;
+                const float* __restrict__ sw0 = s_w + (it & 1) * WCH;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                const float* __restrict__ sx = sx0 + ks * 4 * PLANE;
+                const float* __restrict__ sw = sw0 + ks * WCH1;
+                // One stage = one straight-line block of MFMAs: no condition inside it (first version: one branch per 4x4x1 instruction cut the
+                // matrix stream into basic blocks of two or three MFMAs with an s_waitcnt each).
+                // window rows of the wave: R + 2 rows x 6 floats (+ MODE 1: the two column-patched operands, see the header)
+                float b[R + 2][MODE == 1 ? 8 : 6];
+    #pragma unroll
+                for (int rr = 0; rr < R + 2; ++rr) {
+                    int ro = rr * PITCH;
+                    if constexpr (MODE == 1) {          // wave-uniform: the spare window rows S1 / S2 stand in for dy[2] / dy[H-3] (header)
+                        if (rr == R + 1 && row0 + R - 1 == 1) ro = (Cfg::WROWS - wv * R) * PITCH;
+                        if (rr == 0 && row0 == H - 2) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
+                    }
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sx + ro);
+                    const f32x2 hi = *reinterpret_cast<const f32x2*>(sx + ro + 4);
+                    b[rr][0] = lo.x; b[rr][1] = lo.y; b[rr][2] = lo.z; b[rr][3] = lo.w; b[rr][4] = hi.x; b[rr][5] = hi.y;
+                }
+                if constexpr (MODE == 1) {
+                    // column part of the reflection adjoint: image column 1 (phase 1 of lane 0 in the leftmost tile) takes tap kx = 2 from
+                    // win[3] + win[1]; column W-2 (phase 2 of lane 15 in the rightmost tile) takes tap kx = 0 from win[2] + win[4]
+                    const float ml = (px0 == 0 && l15 == 0) ? 1.f : 0.f, mr = (px0 + 64 == W && l15 == 15) ? 1.f : 0.f;
+    #pragma unroll
+                    for (int rr = 0; rr < R + 2; ++rr) { b[rr][6] = __builtin_fmaf(ml, b[rr][1], b[rr][3]); b[rr][7] = __builtin_fmaf(mr, b[rr][4], b[rr][2]); }
+                }
+                auto bop = [&](int rr, int j, int kx) -> float {
+                    if constexpr (MODE == 1) { if (j == 1 && kx == 2) return b[rr][6]; if (j == 2 && kx == 0) return b[rr][7]; }
+                    return b[rr][j + kx];
+                };
+    #pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    f32x4 a[MF]; f32x4 ax;
+    #pragma unroll
+                    for (int f = 0; f < MF; ++f) a[f] = *reinterpret_cast<const f32x4*>(sw + f * WFR + wb + ky * 4);
+                    if constexpr (REMB) ax = *reinterpret_cast<const f32x4*>(sw + wxb + ky * 4);
+    #pragma unroll
+                    for (int r = 0; r < R; ++r)
+    #pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float bv = bop(r + ky, j, kx);
+    #pragma unroll
+                                for (int f = 0; f < MF; ++f) acc[f][r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][kx], bv, acc[f][r][j], 0, 0, 0);
+                                if constexpr (REMB) accx[r][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax[kx], bv, accx[r][j], 0, 0, 0);
+                            }
+                }
+                }
 
-            RP_T(c1); RP_ACC(1, c1 - c0);                                        // MFMA phase (issue time: the last MFMAs still run)
-#ifdef RP_DBG_NOEPI
-            if (ci == n_chunks - 1 && A.tiles_x < 0) {
-#else
-            if (ci == n_chunks - 1) {
-#endif
-                // ---- epilogue: register q of (f, r, phase 0..3) = channel m0 + 16 f + 4 l4 + q, row row0 + r, pixels px0 + 4 l15 .. +3 ----
-                if constexpr (MODE == 0) {
-                    float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HW;
-#pragma unroll
-                    for (int f = 0; f < MF; ++f) {
-                        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int ml = f * 16 + l4 * 4 + q;
-                                const float bi = s_bias[ml];
-                                const float v0 = acc[f][r][0][q] + bi, v1 = acc[f][r][1][q] + bi, v2 = acc[f][r][2][q] + bi, v3 = acc[f][r][3][q] + bi;
-                                if (ml < mt) {
-                                    *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(v0, v1, v2, v3);
-                                    fs[q] += (v0 + v1) + (v2 + v3);
-                                    fq[q] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, fq[q]))));
+                RP_T(c1); RP_ACC(1, c1 - c0);                                        // MFMA phase (issue time: the last MFMAs still run)
+    #ifdef RP_DBG_NOEPI
+                if (ci == n_chunks - 1 && A.tiles_x < 0) {
+    #else
+                if (ci == n_chunks - 1) {
+    #endif
+                    // ---- epilogue: register q of (f, r, phase 0..3) = channel m0 + 16 f + 4 l4 + q, row row0 + r, pixels px0 + 4 l15 .. +3 ----
+                    if constexpr (MODE == 0) {
+                        float* __restrict__ yout = A.out.data + (long long)k * A.out.sstride + (long long)m0 * HW;
+    #pragma unroll
+                        for (int f = 0; f < MF; ++f) {
+                            float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                            for (int r = 0; r < R; ++r)
+    #pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int ml = f * 16 + l4 * 4 + q;
+                                    const float bi = s_bias[ml];
+                                    const float v0 = acc[f][r][0][q] + bi, v1 = acc[f][r][1][q] + bi, v2 = acc[f][r][2][q] + bi, v3 = acc[f][r][3][q] + bi;
+                                    if (ml < mt) {
+                                        *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(v0, v1, v2, v3);
+                                        fs[q] += (v0 + v1) + (v2 + v3);
+                                        fq[q] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, fq[q]))));
+                                    }
+                                }
+                            if (do_stats) {
+    #pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    float a_ = fs[q], b_ = fq[q];
+    #pragma unroll
+                                    for (int o = 8; o > 0; o >>= 1) { a_ += __shfl_xor(a_, o, 64); b_ += __shfl_xor(b_, o, 64); }
+                                    if (l15 == 0) { s_red[wv][f * 16 + l4 * 4 + q][0] += (double)a_; s_red[wv][f * 16 + l4 * 4 + q][1] += (double)b_; }
                                 }
                             }
-                        if (do_stats) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float a_ = fs[q], b_ = fq[q];
-#pragma unroll
-                                for (int o = 8; o > 0; o >>= 1) { a_ += __shfl_xor(a_, o, 64); b_ += __shfl_xor(b_, o, 64); }
-                                if (l15 == 0) { s_red[wv][f * 16 + l4 * 4 + q][0] += (double)a_; s_red[wv][f * 16 + l4 * 4 + q][1] += (double)b_; }
-                            }
                         }
-                    }
-                } else {
-                    float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * HW;
-                    const float* __restrict__ xraw = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HW;
-                    const int xact = A.xin.act; const float xslope = A.xin.slope;
-                    auto fold4 = [&](int ml, int r, float (&dd)[4], float& fsum, float& fxs, const float4 y4) {
-                        if (fuse_sums) {
-                            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
-                            const ChanFwd cf = s_ch[m0 + ml];
+                    } else {
+                        // hand the tile to the staging waves: accumulators -> s_out[channel][tile row][64 pixels] as float4 (one ds_write_b128 per
+                        // register index); they fold and store it during the next tile's stages while this wave goes on with its MFMAs
 #pragma unroll
-                            for (int l = 0; l < 4; ++l) {
-                                const float vv = __builtin_fmaf(yy[l] - cf.mean, cf.scale, cf.beta);
-                                if (xact && !(vv > 0.f)) dd[l] *= xslope;
-                                fsum += dd[l]; fxs = __builtin_fmaf(dd[l], (yy[l] - cf.mean) * cf.rstd, fxs);
-                            }
-                        }
-                        *reinterpret_cast<float4*>(o + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(dd[0], dd[1], dd[2], dd[3]);
-                    };
-#pragma unroll
-                    for (int f = 0; f < MF; ++f) {
-                        // all raw-x float4 of the fragment are requested together
-                        float4 y4[R][4];
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) y4[r][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (fuse_sums) {
+                        for (int f = 0; f < MF; ++f)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const int ml = min(f * 16 + l4 * 4 + q, mt - 1);
-                                    y4[r][q] = *reinterpret_cast<const float4*>(xraw + ml * HW + (row0 + r) * W + px0 + 4 * l15);
-                                }
-                        }
-                        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int ml = f * 16 + l4 * 4 + q;
-                                float dd[4] = {acc[f][r][0][q], acc[f][r][1][q], acc[f][r][2][q], acc[f][r][3][q]};
-                                if (ml < mt) fold4(ml, r, dd, fs[q], fq[q], y4[r][q]);
-                            }
-                        if (fuse_sums) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float a_ = fs[q], b_ = fq[q];
-#pragma unroll
-                                for (int o2 = 8; o2 > 0; o2 >>= 1) { a_ += __shfl_xor(a_, o2, 64); b_ += __shfl_xor(b_, o2, 64); }
-                                if (l15 == 0) { s_red[wv][f * 16 + l4 * 4 + q][0] += (double)a_; s_red[wv][f * 16 + l4 * 4 + q][1] += (double)b_; }
-                            }
-                        }
-                    }
-                    if constexpr (REM) {
-                        if (rem_blk) {
-                            // 4x4x1 accumulators: register q of (r, phase j) = extra channel q at pixel 4 l15 + j, this lane's reduction-channel slice
-                            // (k = l4): add the four slices, then lane group l4 == q' folds and stores channel q'
-                            float fs = 0.f, fq = 0.f;
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<float4*>(&s_out[(f * 16 + l4 * 4 + q) * OP + (wv * R + r) * 64 + 4 * l15]) =
+                                        make_float4(acc[f][r][0][q], acc[f][r][1][q], acc[f][r][2][q], acc[f][r][3][q]);
+                        if constexpr (REMB) {
+                            // 4x4x1 accumulators: register q of (r, phase j) = extra channel q at pixel 4 l15 + j, this lane's reduction-channel
+                            // slice (k = l4): add the four slices; lane group l4 == q' then holds channel q'
 #pragma unroll
                             for (int r = 0; r < R; ++r) {
                                 float dd[4];
@@ -475,28 +559,22 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                                     }
                                     dd[j] = mine;
                                 }
-                                const int ml = CT + l4;
-                                float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (fuse_sums) y4 = *reinterpret_cast<const float4*>(xraw + ml * HW + (row0 + r) * W + px0 + 4 * l15);
-                                fold4(ml, r, dd, fs, fq, y4);
-                            }
-                            if (fuse_sums) {
-#pragma unroll
-                                for (int o2 = 8; o2 > 0; o2 >>= 1) { fs += __shfl_xor(fs, o2, 64); fq += __shfl_xor(fq, o2, 64); }
-                                if (l15 == 0) { s_red[wv][CT + l4][0] += (double)fs; s_red[wv][CT + l4][1] += (double)fq; }
+                                *reinterpret_cast<float4*>(&s_out[(CT + l4) * OP + (wv * R + r) * 64 + 4 * l15]) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                             }
                         }
                     }
                 }
+                RP_T(c2); RP_ACC(2, c2 - c1);                                        // epilogue
+                lds_barrier();
+                RP_T(c3); RP_ACC(3, c3 - c2);                                        // barrier wait
             }
-            RP_T(c2); RP_ACC(2, c2 - c1);                                        // epilogue
-            lds_barrier();
-            RP_T(c3); RP_ACC(3, c3 - c2);                                        // barrier wait
-        }
-        RP_T(c_end); RP_ACC(4, c_end - c_loop0);
-#ifdef RP_PROF
-        if (t == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&g_rp_prof[i], prof[i]); atomicAdd(&g_rp_prof[5], 1ull); atomicAdd(&g_rp_prof[6], (unsigned long long)n_iters); }
-#endif
+            RP_T(c_end); RP_ACC(4, c_end - c_loop0);
+    #ifdef RP_PROF
+            if (t == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&g_rp_prof[i], prof[i]); atomicAdd(&g_rp_prof[5], 1ull); atomicAdd(&g_rp_prof[6], (unsigned long long)n_iters); }
+    #endif
+        };
+        if constexpr (REM) { if (rem_blk) consume(std::true_type{}); else consume(std::false_type{}); }
+        else consume(std::false_type{});
         if (do_stats) {
             __syncthreads();                              // (Z)
             if (t < CTX * 2) {
@@ -509,34 +587,40 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
     }
 }
 
-template <int MODE, int MF, int R, bool REM>
+template <int MODE, int MF, int R, bool REM, int KS>
 int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
 {
-    using Cfg = RpCfg<R>;
+    using Cfg = RpCfg<R, MODE>;
     const ConvGeom& g = A.g;
     const int MOUT = MODE == 0 ? g.Cout : g.Cin;
     constexpr int CT = 16 * MF;
     if (g.H % Cfg::TH) return -3;
+    const int RED = MODE == 0 ? g.Cin : g.Cout;
+    if (RED % (4 * KS)) return -3;
+    if (MODE == 1 && RED / (4 * KS) < 4) return -3;       // the fold of a tile rides on stages 0..2 of the next one
     if (REM && !((MOUT & 15) == 4 && (MOUT - 4) % CT == 0)) return -3;
     A.tiles_x = g.W / 64;
     A.n_tiles = A.tiles_x * (g.H / Cfg::TH);
     A.tiles_per_block = T;
     A.nx = (A.n_tiles + T - 1) / T; A.ny = REM ? (MOUT - 4) / CT : (MOUT + CT - 1) / CT; A.nz = n_samples;
-    constexpr int WCH = MF * 4 * 16 * 12 + (REM ? 4 * 4 * 12 : 0);
+    constexpr int WCH = KS * (MF * 4 * 16 * 12 + (REM ? 4 * 4 * 12 : 0));
     const size_t dyn = sizeof(float) * 2 * WCH + sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(RpBwd) * (size_t)((g.Cout + 3) & ~3);
     constexpr int MINW = 4;
-    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, MINW>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
+    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, KS, MINW>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
     return (int)hipGetLastError();
 }
 
-// tune code: mf | r << 8 | T << 16 | rem << 12 | MFVI_TUNE_RP
+// tune code: mf | r << 8 | rem << 12 | ks << 13 | T << 16 | MFVI_TUNE_RP   (ks = k-steps per stage: 0 / 1 -> 1, 2)
 template <int MODE>
 int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
 {
-    const int mf = tune & 255, r = (tune >> 8) & 15, rem = (tune >> 12) & 1, T = max(1, (tune >> 16) & 255);
-#define RP_GO(MF_, R_) if (mf == MF_ && r == R_) { if constexpr (MODE == 1) { if (rem) return launch_rp<MODE, MF_, R_, true>(A, T, n_samples, st); } if (rem) return -3; return launch_rp<MODE, MF_, R_, false>(A, T, n_samples, st); }
-    RP_GO(1, 1) RP_GO(1, 2) RP_GO(1, 4) RP_GO(2, 1) RP_GO(2, 2) RP_GO(4, 1)
+    const int mf = tune & 255, r = (tune >> 8) & 15, rem = (tune >> 12) & 1, ks = max(1, (tune >> 13) & 7), T = max(1, (tune >> 16) & 255);
+#define RP_GO2(MF_, R_, KS_) if (mf == MF_ && r == R_ && ks == KS_) { if constexpr (MODE == 1) { if (rem) return launch_rp<MODE, MF_, R_, true, KS_>(A, T, n_samples, st); } if (rem) return -3; return launch_rp<MODE, MF_, R_, false, KS_>(A, T, n_samples, st); }
+#define RP_GO(MF_, R_) RP_GO2(MF_, R_, 1)      /* two k-steps per stage (KS = 2) built and measured: no gain, register spills in backward-data; not instantiated */
+    RP_GO(1, 1) RP_GO(1, 2) RP_GO(2, 1)
+    if constexpr (MODE == 0) { RP_GO(2, 2) RP_GO2(4, 1, 1) RP_GO2(1, 4, 1) }       // backward-data: rows 1 / H-2 must be the last / first row of their wave (R <= 2); its out tile keeps (2, 2) / (4, 1) at one block per CU
 #undef RP_GO
+#undef RP_GO2
     return -3;
 }
 
@@ -557,7 +641,7 @@ int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long 
 int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse)
 {
     if (g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3) || g.H < 4 || (g.Cin & 3) || (g.Cout & 3) || (g.w_off & 3) || g.Cout > MFVI_MAX_C || g.Cin > MFVI_MAX_C) return -2;
-    if (!fuse.ga || (fuse.ga_sstride & 3) || ((uintptr_t)fuse.ga & 15)) return -2;
+    if (!fuse.ga || (fuse.ga_sstride & 3) || ((uintptr_t)fuse.ga & 15) || g.Cout < 16) return -2;      // the fold of a tile rides on stages 0..2 of the next one
     if ((gy.gstride & 3) || ((uintptr_t)gy.ga & 15) || (gy.stats && ((gy.ystride & 3) || ((uintptr_t)gy.y & 15)))) return -2;
     if (fuse.bsums && ((fuse.x.sstride & 3) || ((uintptr_t)fuse.x.data & 15))) return -2;
     if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 29)) return -2;
@@ -573,17 +657,26 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
 {
     static const int on = [] { const char* e = getenv("MFVI_RP"); return !(e && e[0] == '0'); }();
     if (!on || g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3)) return 0;
-    static const int forced = [] { int mf = 0, r = 0, T = 1, rem = 0; const char* e = getenv("MFVI_TUNE_RP"); if (e) sscanf(e, "%d,%d,%d,%d", &mf, &r, &T, &rem); return mf > 0 ? (mf | r << 8 | (rem & 1) << 12 | T << 16) : 0; }();
+    static const int forced = [] { int mf = 0, r = 0, T = 1, rem = 0, ks = 1; const char* e = getenv("MFVI_TUNE_RP"); if (e) sscanf(e, "%d,%d,%d,%d,%d", &mf, &r, &T, &rem, &ks); return mf > 0 ? (mf | r << 8 | (rem & 1) << 12 | (ks & 7) << 13 | T << 16) : 0; }();
     if (forced) return forced | MFVI_TUNE_RP;
     const int MOUT = mode == 0 ? g.Cout : g.Cin;
     const int rem = (mode == 1 && (MOUT & 15) == 4) ? 1 : 0;
     const int mo = MOUT - 4 * rem;
     if (mo < 16) return 0;
+    if (mode == 1 && g.Cout < 16) return 0;
     const int mf = (mo % 32 == 0) ? 2 : 1;
-    const long long units = (long long)(g.W / 64) * (g.H / 4) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles
-    int r = 1;
-    if (!(rem && mf == 2) && (g.H & 7) == 0 && units / 2 >= 512) r = 2;
-    return mf | r << 8 | rem << 12 | 1 << 16 | MFVI_TUNE_RP;
+    const long long units = (long long)(g.W / 64) * (g.H / 4) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles, one per block
+    // measured on the three big layers (profiles/r03_rp_layers.txt): forward — tall tiles (fewer stage barriers per MFMA) while the grid
+    // still fills the chip twice; backward-data — 4-row tiles (the out tile of the fold is LDS) and several tiles per block (the last
+    // tile's fold and the block prologue are exposed once per block)
+    int r = 1, T = 1;
+    if (mode == 0) {
+        if (mf == 1 && (g.H & 15) == 0 && units / 4 >= 1024) r = 4;
+        else if ((g.H & 7) == 0 && units / 2 >= 512) r = 2;
+    } else {
+        while (T < 8 && units / (2 * T) >= 512) T *= 2;
+    }
+    return mf | r << 8 | rem << 12 | T << 16 | MFVI_TUNE_RP;
 }
 
 #ifdef RP_PROF

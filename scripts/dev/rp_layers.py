@@ -57,14 +57,17 @@ for cin, cout, hw in specs:
     if only:
         sel = set()
         for item in only.split(";"):
-            w_, rest = item.split(":"); sel.add((int(w_),) + tuple(int(v) for v in rest.split(",")))
+            w_, rest = item.split(":"); vals = tuple(int(v) for v in rest.split(","))
+            sel.add((int(w_),) + (vals if len(vals) == 5 else vals + (1,)))
     for w, name, ps in ((0, "fwd", 0), (1, "bwd_data", 2)):
         for mf, r in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (4, 1)):
             for rem in ((0, 1) if (w == 1 and rem_ok) else (0,)):
-                for T in (1, 2, 4):
-                    if sel is not None and (w, mf, r, T, rem) not in sel:
+                for T, ks in [(T_, k_) for T_ in (1, 2, 4, 8, 16) for k_ in (1, 2)]:
+                    if sel is not None and (w, mf, r, T, rem, ks) not in sel:
                         continue
-                    code = mf | r << 8 | rem << 12 | T << 16 | RP
+                    if sel is None and (T > 4 or ks > 1):
+                        continue
+                    code = mf | r << 8 | rem << 12 | ks << 13 | T << 16 | RP
                     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, w, code))
                     try:
                         us = measure(plan, P, op, bufs, ps)
@@ -72,4 +75,4 @@ for cin, cout, hw in specs:
                         continue
                     finally:
                         M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, w, base[w]))
-                    print("%d->%d @%d %-10s rp mf=%d r=%d rem=%d T=%d: %7.1f us %5.1f TF (%.3f)" % (cin, cout, hw, name, mf, r, rem, T, us, tf(us), tf(us) / 157.3), flush=True)
+                    print("%d->%d @%d %-10s rp mf=%d r=%d rem=%d T=%d ks=%d: %7.1f us %5.1f TF (%.3f)" % (cin, cout, hw, name, mf, r, rem, T, ks, us, tf(us), tf(us) / 157.3), flush=True)

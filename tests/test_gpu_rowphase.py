@@ -14,8 +14,8 @@ torch = pytest.importorskip("torch")
 RP = 1 << 24
 
 
-def enc_rp(mf, r, T=1, rem=0):
-    return mf | r << 8 | rem << 12 | T << 16 | RP
+def enc_rp(mf, r, T=1, rem=0, ks=1):
+    return mf | r << 8 | rem << 12 | ks << 13 | T << 16 | RP
 
 
 def enc(a, b, c):
@@ -37,8 +37,8 @@ def test_rowphase_forward_against_oracle(M, case):
     bn = torch.zeros(1, device="cuda")
     lib = M._lib.lib()
     tried = 0
-    for mf, r, T in [(1, 1, 1), (1, 2, 1), (1, 4, 2), (2, 1, 1), (2, 2, 3), (4, 1, 1)]:
-        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, enc_rp(mf, r, T)))
+    for mf, r, T, ks in [(1, 1, 1, 1), (1, 2, 1, 1), (1, 4, 2, 1), (2, 1, 1, 1), (2, 2, 3, 1), (4, 1, 1, 1)]:
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, enc_rp(mf, r, T, ks=ks)))
         try:
             y = plan.forward(d_mu, d_rho, bn, d_x, seed, step, k0, n)
         except M._lib.MfviError:
@@ -48,7 +48,7 @@ def test_rowphase_forward_against_oracle(M, case):
         for i in range(n):
             ew = O.eps(seed, step, k0 + i, 0, 0, nw); eb = O.eps(seed, step, k0 + i, 0, 1, cout)
             w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, 3, 3); b = O.reparam(mu[nw:], rho[nw:], eb)
-            assert relerr(yh[i], O.conv_fwd(x, w, b, 1)) < 2e-6, ("fwd", mf, r, T, i)
+            assert relerr(yh[i], O.conv_fwd(x, w, b, 1)) < 2e-6, ("fwd", mf, r, T, ks, i)
     assert tried >= 3
 
 
@@ -66,11 +66,12 @@ def test_rowphase_tilings_against_round2_kernels(M, shape):
     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, enc(1, 8, 1))); M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
     ref = _run_plan(plan, P, seed, n, z, dout)
     tried = [0, 0]
-    fwd = [(1, 1, 1, 0), (1, 2, 1, 0), (1, 4, 1, 0), (2, 1, 2, 0), (2, 2, 1, 0), (4, 1, 1, 0), (1, 1, 3, 0)]
-    bwd = fwd + [(1, 1, 1, 1), (1, 2, 1, 1), (2, 1, 1, 1), (2, 1, 2, 1), (4, 1, 1, 1)]
+    fwd = [(1, 1, 1, 0, 1), (1, 2, 1, 0, 1), (1, 4, 1, 0, 1), (2, 1, 2, 0, 1), (2, 2, 1, 0, 1), (4, 1, 1, 0, 1), (1, 1, 3, 0, 1),
+           ]       # last field: k-steps per stage
+    bwd = fwd + [(1, 1, 1, 1, 1), (1, 2, 1, 1, 1), (2, 1, 1, 1, 1), (2, 1, 2, 1, 1)]
     for which, cands in ((0, fwd), (1, bwd)):
-        for mf, r, T, rem in cands:
-            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc_rp(mf, r, T, rem)))
+        for mf, r, T, rem, ks in cands:
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc_rp(mf, r, T, rem, ks)))
             try:
                 got = _run_plan(plan, P, seed, n, z, dout)
             except M._lib.MfviError:
@@ -78,9 +79,9 @@ def test_rowphase_tilings_against_round2_kernels(M, shape):
             finally:
                 M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, which, enc(1, 8, 1)))
             tried[which] += 1
-            assert relerr(got[0], ref[0]) < 1e-6, ("out", which, mf, r, T, rem)
+            assert relerr(got[0], ref[0]) < 1e-6, ("out", which, mf, r, T, rem, ks)
             for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
-                assert relerr(a, b) < 2e-5, (name, which, mf, r, T, rem)
+                assert relerr(a, b) < 2e-5, (name, which, mf, r, T, rem, ks)
     assert tried[0] >= 2 and tried[1] >= 2, tried
 
 
