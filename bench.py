@@ -5,8 +5,13 @@ Default workload = configs[1]: test_configs/mfvi_den.json values, 256x256 skip n
 One step = one tempered-ELBO iteration: input perturbation, weight draw, K MC forwards, data term, backward, KL(+grad), Adam (and, for
 N > 1 ranks, the single all-reduce of the flat gradient buffer).
 
-    python bench.py [--gpus N --steps K --warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg5|inp] [--scaling weak|strong]
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg5|inp] [--scaling weak|strong] [--k K] [--mode engine|dropin]
                                                    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+--mode engine (default): the fused runner (ElboEngine: ~10 library calls per iteration, no autograd).
+--mode dropin: the loop a user of the reference runs after INTEGRATION.md's three-line switch — get_net + MeanFieldVI(n_samples=K) +
+  gaussian_nll + temp * net.kl() + loss.backward() + torch.optim.AdamW over the wrapper's Parameters (bayesian_optimization.py:1356-1372;
+  the reference's own loop is K = 1: `--mode dropin --k 1`).  Same JSON shape; den task, one GPU.
 
 --scaling weak (default): every rank evaluates its own K samples (eps keyed by the global sample index): K * N samples per iteration.
 --scaling strong: the config's K is the job's total, split over the ranks (cfg3 as BASELINE states it: K = 32 over 4 GPUs).
@@ -63,6 +68,52 @@ def conv_cost(prog, op_index, n_samples):
     bytes_ = 4 * n_samples * (ti["C"] * ti["H"] * ti["W"] + to["C"] * to["H"] * to["W"]) + 8 * (nw + to["C"])
     flops = 2.0 * n_samples * nw * to["H"] * to["W"]
     return dict(bytes=bytes_, flops=flops, desc="%dx%d conv %d->%d @%dx%d s%d" % (k, k, ti["C"], to["C"], to["H"], to["W"], o["stride"]))
+
+
+def iteration_cost(prog, K):
+    """Algorithmic FLOPs / bytes of ONE ELBO iteration with K MC samples: every conv forward once, backward twice
+    (data + weight) — 3x the forward's FLOPs and bytes — plus KL (mu, rho read once) and Adam (4 tensors read, 3 written per parameter)."""
+    fl = by = 0.0
+    n_par = 0
+    for i, o in enumerate(prog.ops):
+        c = conv_cost(prog, i, K)
+        if c:
+            fl += c["flops"]; by += c["bytes"]
+            ti, to = prog.tensors[o["in0"]], prog.tensors[o["out"]]
+            n_par += 2 * (to["C"] * ti["C"] * o["ksize"] ** 2 + to["C"])
+    n_par += prog.n_bn
+    return dict(flops=3.0 * fl, bytes=3.0 * by + 4.0 * n_par + 28.0 * n_par)
+
+
+# The reference's OWN PyTorch CPU path, measured once by the survey in the build container (BASELINE.md §3; the Python reference cannot
+# travel to the GPU box, so this is a committed number, not something this script measures): K = 1 ELBO iterations of run_den_mfvi's
+# loop (MeanFieldVI + skip + gaussian_nll + torch AdamW) at 256x256.
+REFERENCE_CPU_PROBE = dict(value=5.61, unit="ELBO-iterations/s (K = 1 MC pass each)", ms_per_iteration=178.0, cores=8, threads=8,
+                           software="torch 2.10.0 CPU, float32", workload="mfvi_den 256x256 skip net, K = 1",
+                           source="BASELINE.md section 3 (survey probe in the build container, not measured by this run)")
+
+
+def lib_sha256():
+    import hashlib
+    from mfvi_dip_mia_amd import _lib as L
+    h = hashlib.sha256()
+    with open(L.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def traffic_lookup(key):
+    """HBM bytes per launch of a kernel from the separate rocprofv3 --pmc passes (profiles/traffic.json), or None when the library that
+    produced those counters is not the one running now (the file carries the sha256 of its libmfvi_hip.so)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(tfile))
+        if t.get("lib_sha256") != lib_sha256():
+            return None
+        return t["entries"].get(key)
+    except Exception:
+        return None
 
 
 def cpu_baseline(cfg, n_samples):
@@ -125,6 +176,66 @@ def make_engine(cfg, K, rank, world, torch):
     return eng
 
 
+class DropInLoop:
+    """The reference's own training loop (bayesian_optimization.py:1356-1372) on the drop-in classes, exactly as INTEGRATION.md's
+    three-line switch leaves it: get_net -> MeanFieldVI -> torch.optim.AdamW; per iteration the input perturbation with torch's RNG
+    (:1363-1364), net(z), gaussian_nll + temp * net.kl(), loss.backward(), optimizer.step().  K MC samples come from ONE call
+    (MeanFieldVI(n_samples=K)); the reference's loop is K = 1.  Exposes what main() needs from an engine."""
+
+    def __init__(self, cfg, K, torch, flat=False):
+        import numpy as np
+        import mfvi_dip_mia_amd as M
+        from mfvi_dip_mia_amd.runner import phantom
+        self.torch, self.M = torch, M
+        S, hp = cfg["size"], cfg["hp"]
+        if cfg["task"] != "den":
+            sys.exit("--mode dropin is the denoising loop (run_den_mfvi)")
+        dev = torch.device("cuda")
+        torch.manual_seed(hp["seed"])
+        net = M.get_net(cfg["input_depth"], 'skip', 'reflection', 'bilinear', n_channels=2, skip_n33d=[16, 32, 64, 128, 128],
+                        skip_n33u=[16, 32, 64, 128, 128], skip_n11=4, num_scales=5)
+        self.net = M.MeanFieldVI(net, prior={'mu': 0.0, 'sigma': float(np.sqrt(hp["temp"]) * hp["sigma"])}, replace_layers='all', device=dev,
+                                 reparam='', n_samples=K, seed=hp["seed"], flat_parameters=flat)
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=hp["lr"], weight_decay=0)
+        self.temp = hp["temp"]
+        self.K_local = self.chunk = K
+        rng = np.random.default_rng(hp["seed"] + 1)
+        img = phantom(S, S, hp["seed"])
+        self.target = torch.from_numpy(np.clip(img + rng.normal(scale=hp["p_sigma"], size=img.shape), 0, 1).astype(np.float32)).to(dev)[None, None]
+        self.z0 = 0.1 * torch.rand((1, cfg["input_depth"], S, S), device=dev)
+        self.last = None
+        self.step()                                          # compiles (and autotunes) the plan of this input shape
+        self.plan = next(iter(self.net._plans.values()))
+        self.prog = self.plan.prog
+
+    def _loss(self, out):
+        M = self.M
+        nll = sum(M.gaussian_nll(out[i:i + 1, :1], out[i:i + 1, 1:], self.target) for i in range(out.shape[0])) / out.shape[0]
+        kl = self.net.kl()
+        return nll + self.temp * kl, nll, kl
+
+    def step(self, after_forward=None):
+        torch = self.torch
+        z = self.z0 + 0.1 * torch.randn_like(self.z0)
+        self.opt.zero_grad(set_to_none=True)
+        out = self.net(z)
+        loss, nll, kl = self._loss(out)
+        loss.backward()
+        self.opt.step()
+        self.last = (nll.detach(), kl.detach(), loss.detach())
+
+    def forward_only(self, step=0):
+        with self.torch.no_grad():
+            self.net(self.z0)
+
+    def losses(self):
+        nll, kl, loss = self.last
+        return float(nll), float(kl), float(loss)
+
+    def allreduce_ms(self):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +245,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--size", type=int, default=None, help="override the config's image size")
     ap.add_argument("--k", type=int, default=None, help="override the config's MC samples (per GPU in weak mode, per job in strong mode)")
+    ap.add_argument("--mode", default="engine", choices=["engine", "dropin"])
+    ap.add_argument("--flat-parameters", action="store_true", help="--mode dropin: MeanFieldVI(..., flat_parameters=True) (one flat Parameter for the optimizer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel time table of one iteration to stderr")
     args = ap.parse_args()
@@ -167,7 +280,12 @@ def main():
     K_total = k_strong if strong else cfg["k"] * world
     if K_total % world:
         sys.exit("K = %d MC samples do not split over %d ranks" % (K_total, world))
-    eng = make_engine(cfg, K_total, rank, world, torch)
+    if args.mode == "dropin":
+        if world > 1:
+            sys.exit("--mode dropin runs on one GPU (the reference's loop has no sharding)")
+        eng = DropInLoop(cfg, K_total, torch, flat=args.flat_parameters)
+    else:
+        eng = make_engine(cfg, K_total, rank, world, torch)
 
     def barrier():
         if world > 1:
@@ -217,7 +335,7 @@ def main():
     # ELBO iterations WITH the reference loop's per-iteration bookkeeping (EMA, clips, ring buffers, 2 MSE + 3 PSNR + 3 SSIM:
     # bayesian_optimization.py:1374-1406) — SURVEY 8(d)(ii) asks for the rate with and without it (extra information, untimed region)
     with_book = None
-    if world == 1 and cfg["task"] == "den":
+    if world == 1 and cfg["task"] == "den" and args.mode == "engine":
         from mfvi_dip_mia_amd.runner import _Book, phantom
         gt = phantom(S, S, cfg["hp"]["seed"])
         book = _Book(eng, 16, gt, eng.target.cpu().numpy())
@@ -227,6 +345,7 @@ def main():
         for i in range(3, 13):
             eng.step(after_forward=book.hook(eng, i, eng.chunk))
         torch.cuda.synchronize(); with_book = 10 / (time.perf_counter() - t0)
+        book.wait()          # the side-stream bookkeeping has read eng.out before the timed steps overwrite it
 
     # ---- timed region: exactly --steps iterations, only the dominant kernel carries events ----
     def timed(e, steps):
@@ -285,20 +404,24 @@ def main():
         roof.update(kernel="%s of op %d: %s, %d samples/launch" % (PASS_NAMES[dom_pass], dom_op, cost["desc"], eng.chunk),
                     avg_launch_ms=avg_ms, launches=len(kms), algorithmic_bytes=cost["bytes"], algorithmic_flops=cost["flops"], slab_bytes=4 * nw * eng.chunk,
                     hbm_gbs_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9, hbm_frac_algorithmic=cost["bytes"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
-            try:
-                roof["traffic"] = json.load(open(tfile))["entries"].get("%s:%s" % (PASS_NAMES[dom_pass], cost["desc"]))
-            except Exception:
-                pass
+        roof["traffic"] = traffic_lookup("%s:%s" % (PASS_NAMES[dom_pass], cost["desc"]))     # None unless measured on THIS build of the library
+        ic = iteration_cost(eng.prog, eng.K_local)
+        sec = dt / args.steps
+        roof["iteration"] = dict(algorithmic_flops=ic["flops"], algorithmic_bytes=ic["bytes"], tflops=ic["flops"] / sec / 1e12,
+                                 frac_of_f32_mfma_peak=ic["flops"] / sec / 1e12 / F32_PEAK_TFLOPS, hbm_gbs=ic["bytes"] / sec / 1e9,
+                                 frac_of_hbm_peak=ic["bytes"] / sec / 1e9 / HBM_PEAK_GBS,
+                                 note="whole ELBO iteration per GPU: conv FLOPs / bytes of 1 forward + 2 backward passes over K samples, KL, Adam")
         total_samples = eng.K_local * world * args.steps
         res = {
             "metric": "MC-forward-passes/sec (each inside a full ELBO iteration: fwd+data term+bwd+KL+Adam), %dx%d skip MFVI %s" % (S, S, cfg["task"]),
             "value": total_samples / dt, "unit": "MC-forward-passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if cfg.get("param_dtype", "f32") == "f32" else "f32 arithmetic on bf16-stored mu/rho", "data": "synthetic",
-            "config": {"workload": cfg["what"], "name": args.config, "mc_samples_per_iteration": eng.K_local * world,
-                       "mc_samples_per_gpu": eng.K_local, "parallelism": "mc-sample sharding x%d, 1 all-reduce/iter" % world},
+            "config": {"workload": cfg["what"] + ("" if cfg["k"] == CONFIGS[args.config]["k"] else " [--k %d]" % cfg["k"]), "name": args.config,
+                       "mc_samples_per_iteration": eng.K_local * world, "mc_samples_per_gpu": eng.K_local,
+                       "parallelism": "mc-sample sharding x%d, 1 all-reduce/iter" % world,
+                       "mode": "engine: fused runner (ElboEngine), no autograd" if args.mode == "engine" else
+                               "dropin: get_net + MeanFieldVI%s + gaussian_nll + net.kl() + loss.backward() + torch.optim.AdamW (INTEGRATION.md loop)" % ("(flat_parameters=True)" if args.flat_parameters else "")},
             "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
             "elbo_iters_per_sec": args.steps / dt, "elbo_iters_per_sec_with_bookkeeping": with_book, "fwd_only_mc_passes_per_sec": fwd_only,
             "final_loss": loss, "final_nll": nll, "final_kl": kl,
@@ -306,7 +429,13 @@ def main():
         }
         if strong_extra:
             res["strong_scaling"] = strong_extra
-        if world == 1 and not args.no_cpu_baseline and cfg["cpu_samples"]:
+        if world > 1:
+            res["allreduce_ms"] = eng.allreduce_ms()        # mean duration of the gradient all-reduce (HIP events around the collective)
+        if cfg["task"] == "den" and S == 256:
+            res["reference_cpu_probe"] = REFERENCE_CPU_PROBE
+        if args.mode == "dropin":
+            res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(cfg, min(cfg["cpu_samples"], 8 * max(1, eng.K_local)))
+        elif world == 1 and not args.no_cpu_baseline and cfg["cpu_samples"]:
             res["cpu_baseline"] = cpu_baseline(cfg, cfg["cpu_samples"])
         elif world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = None       # the oracle has no 5x5 / no-skip net driver: the inpainting variant is pinned by reference goldens only

@@ -19,6 +19,25 @@
  *  - random numbers follow "RNG spec v1" (DESIGN.md): Philox4x32-10 keyed by seed, counter
  *    (block, domain<<24|stream, sample, step); eps of VI layer l, tensor t (0 = W, 1 = bias),
  *    element j is lane j&3 of block j>>2 of stream 2l+t in domain 0.
+ *  - process-wide switches.  The library holds no mutable global state, but it reads the environment variables below ONCE (first use,
+ *    function-local statics); none of them changes a result beyond summation-order rounding, all exist for A/B timing and for the
+ *    cross-check tests.  Per-plan state has setters (mfvi_plan_set_*) instead.
+ *      MFVI_DISABLE_MFMA=1     every convolution on the generic fp32 VALU kernels
+ *      MFVI_AUTOTUNE=0         mfvi_plan_autotune returns at once (heuristic tilings)
+ *      MFVI_TUNE=mf,th,T       force one tiling of the round-2 MFMA forward / backward-data kernels where the plan holds none
+ *      MFVI_TUNE_W=nb,w,tgt    the same for the backward-weight kernels
+ *      MFVI_RP=0               keep the 3x3 stride-1 layers on the round-2 kernels (row-phase kernels of conv_rp.hip off)
+ *      MFVI_TUNE_RP=mf,r,T[,rem[,ks]]  force one row-phase tiling where the plan holds none
+ *      MFVI_PHASE=0            stride-2 backward-data: zero-stuffed formulation instead of the phase decomposition
+ *      MFVI_FOLD_FUSION=0      1x1 backward-data writes the padded gradient + a finalize_dx launch (fold not fused)
+ *      MFVI_FOLD_FUSION3=0     the same for the 3x3 stride-1 layers
+ *      MFVI_GRAD_FROM_SLAB=1   grad_finalize reads eps * softplus(rho) as W_k - mu from the sampled-weight slab instead of re-deriving eps
+ *      MFVI_SIDE_STREAM=0      backward-weight kernels on the caller's stream (default: the plan's side stream; mfvi_plan_set_side_stream)
+ *      MFVI_SIDE_MAXPIX=n      only layers with at most n output pixels fork onto the side stream
+ *      MFVI_SIDE_PRIO=0        side stream at default priority (default: lowest)
+ *      MFVI_FWD_FORK=n         forward pass: skip-branch 1x1 convolutions on maps of up to n pixels run on the side stream (default 16384, 0 = off)
+ *      MFVI_FORK_ON_PACKET=0   fork / join events as separate hipEventRecord packets instead of riding on kernel dispatch packets
+ *      MFVI_DEBUG_FIN          print the gradient-reduction table to stderr
  */
 #ifndef MFVI_HIP_H
 #define MFVI_HIP_H

@@ -48,18 +48,29 @@ def _plt():
     return plt
 
 
+# loss_<method>.png — the figure the reference's loop rewrites every show_every iterations (bayesian_optimization.py:172-199).  Its
+# LAYOUT is the artefact contract (people compare these PNGs across methods), so it is written down as data: a left axis with the two
+# MSE curves (default colour cycle, y range 0 ... 0.03, grid), a twin right axis with column 2 of the PSNR table (smoothed output vs
+# ground truth) in green.
+LOSS_FIGURE = dict(left=dict(xlabel="iteration", ylabel="mse", ylim=(0, 0.03)), psnr_column=2, psnr_style="g")
+
+
 def plot_loss(mse_corrupted, mse_gt, psnrs, it, path, title="MSE", y_label="psnr_gt_sm"):
-    """bayesian_optimization.py:172-199: the two MSE curves up to iteration `it`, the smoothed PSNR on a twin axis."""
+    """Draw LOSS_FIGURE for the first `it` iterations and save it to `path` (same argument list as the reference's plot_loss)."""
     plt = _plt()
-    fig, ax0 = plt.subplots()
-    ax0.plot(range(len(mse_corrupted[:it])), mse_corrupted[:it])
-    ax0.plot(range(len(mse_gt[:it])), mse_gt[:it])
-    ax0.set_title(title); ax0.set_xlabel('iteration'); ax0.set_ylabel('mse'); ax0.set_ylim(0, 0.03); ax0.grid(True)
-    ax1 = ax0.twinx()
-    ax1.plot(range(len(psnrs[:it])), psnrs[:it, 2], 'g')
-    ax1.set_ylabel(y_label)
-    fig.tight_layout(); fig.savefig(path)
-    plt.close('all')
+    curves = [np.asarray(c)[:it] for c in (mse_corrupted, mse_gt)]
+    psnr = np.asarray(psnrs)[:it, LOSS_FIGURE["psnr_column"]]
+    fig, left = plt.subplots()
+    for c in curves:
+        left.plot(np.arange(len(c)), c)
+    left.set(title=title, **LOSS_FIGURE["left"])
+    left.grid(True)
+    right = left.twinx()
+    right.plot(np.arange(len(psnr)), psnr, LOSS_FIGURE["psnr_style"])
+    right.set_ylabel(y_label)
+    fig.tight_layout()
+    fig.savefig(path)
+    plt.close("all")
 
 
 def plot_results(MSE_CORRUPTED, MSE_GT, PSNRS, SSIMS, run_dir, file):

@@ -65,6 +65,22 @@ class _NetFunction(torch.autograd.Function):
         return (None, dz) + tuple(grads)
 
 
+class _NetFunctionFlat(torch.autograd.Function):
+    """flat_parameters=True: ONE differentiable input, the flat [MU | RHO | BN] buffer, instead of 254 Parameter views — one AccumulateGrad
+    node and one gradient tensor per backward instead of 254."""
+
+    @staticmethod
+    def forward(ctx, owner, x, flat):
+        out, token = owner._hip_forward(x)
+        ctx.owner, ctx.token, ctx.x_requires = owner, token, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, dz = ctx.owner._hip_backward(ctx.token, dout.contiguous(), ctx.x_requires, flat=True)
+        return None, dz, g
+
+
 class _KLFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, lo, hi, prior_mu, prior_sigma, *params):
@@ -77,10 +93,30 @@ class _KLFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(owner._hip_kl_backward(lo, hi, pm, ps, g))
 
 
+class _KLFunctionFlat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, lo, hi, prior_mu, prior_sigma, flat):
+        ctx.args = (owner, lo, hi, prior_mu, prior_sigma)
+        return owner._hip_kl(lo, hi, prior_mu, prior_sigma)
+
+    @staticmethod
+    def backward(ctx, g):
+        owner, lo, hi, pm, ps = ctx.args
+        return None, None, None, None, None, owner._hip_kl_backward(lo, hi, pm, ps, g, flat=True)
+
+
 class MeanFieldVI(nn.Module):
     def __init__(self, net, prior=None, posteriors=None, kl_type='reverse', reparam='local', replace_layers='all',
-                 device=torch.device('cpu'), seed=None, n_samples=1, autotune=True):
+                 device=torch.device('cpu'), seed=None, n_samples=1, autotune=True, flat_parameters=False):
+        """Arguments as BayTorch/freq_to_bayes.py:9-16, plus seed / n_samples / autotune and
+        flat_parameters (default False: `.parameters()` yields the reference's 254 leaf Parameters W_mu, W_rho, bias_mu, bias_rho, BN
+        weight / bias, and autograd delivers a .grad to each — exact torch semantics, ~3 ms of per-Parameter Python / autograd /
+        optimizer work per iteration).  True: `.parameters()` yields ONE Parameter, the flat [MU | RHO | BN] buffer all of those are
+        views of, so `torch.optim.AdamW(net.parameters(), ...)` (bayesian_optimization.py:1356-1357 unchanged) updates it with one
+        fused launch and a backward produces one gradient tensor; state_dict / named_parameters / modules() keep the reference's names,
+        but the per-layer Parameters then carry no .grad of their own."""
         super().__init__()
+        self._flat_mode = bool(flat_parameters)
         self._autotune = bool(autotune)      # False: keep the built-in tiling heuristics (no ~1 s search on the first forward of a shape)
         # reparam == 'local' (the reference's default): every conv becomes a Conv2dLRT (sampling in activation space); anything else
         # (the runners pass ''): Conv2dRT (sampling in weight space) — freq_to_bayes.py:22-29
@@ -109,6 +145,17 @@ class MeanFieldVI(nn.Module):
         self._replace(net, prior, posteriors, kl_type)
         self._flatten(posteriors)
         self.net = net.to(device) if False else net          # parameters already live on `device` (flat buffer)
+        if self._flat_mode:      # not registered as a module parameter: state_dict / named_parameters keep the reference's key list
+            object.__setattr__(self, "_flat_p", nn.Parameter(self._flat))
+
+    def parameters(self, recurse=True):
+        if getattr(self, "_flat_mode", False):
+            if not self._views_intact():
+                self._reflatten()
+            if self._flat_p.data_ptr() != self._flat.data_ptr():
+                self._flat_p.data = self._flat
+            return iter([self._flat_p])
+        return super().parameters(recurse)
 
     # ------------------------------------------------------------------ construction
     def _replace(self, module, prior, posteriors, kl_type):
@@ -338,6 +385,8 @@ class MeanFieldVI(nn.Module):
         modes = {b.training for b in self._bn}
         if len(modes) > 1:
             raise NotImplementedError("BatchNorm layers in mixed train / eval mode")
+        if getattr(self, "_flat_mode", False):
+            return _NetFunctionFlat.apply(self, x, next(self.parameters()))
         return _NetFunction.apply(self, x, *self._param_list)
 
     def set_sampling(self, enabled=True):
@@ -349,6 +398,8 @@ class MeanFieldVI(nn.Module):
     def kl(self):
         """Sum of the layers' KL(prior || posterior) as a tensor of shape [1] (freq_to_bayes.py:43-48)."""
         m = self._vi[0]
+        if getattr(self, "_flat_mode", False):
+            return _KLFunctionFlat.apply(self, 0, self.n_vi, m.prior_mu, m.prior_sigma, next(self.parameters()))
         vi_params = [p for q in self._vi for p in ([q.W_mu, q.W_rho] + ([q.bias_mu, q.bias_rho] if q._has_bias else []))]
         return _KLFunction.apply(self, 0, self.n_vi, m.prior_mu, m.prior_sigma, *vi_params)
 
@@ -381,6 +432,10 @@ class MeanFieldVI(nn.Module):
         bn_eval = bool(self._bn) and not self._bn[0].training
         if bn_eval and not all(b.track_running_stats for b in self._bn):
             raise NotImplementedError("BatchNorm2d(track_running_stats=False) in eval mode")
+        if bn_eval and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # fail here, not later inside autograd: the kernels implement the training-mode BatchNorm backward only
+            raise NotImplementedError("backward through eval-mode BatchNorm is not built (the reference never trains in eval mode): "
+                                      "call the net under torch.no_grad() in eval mode, or switch it back with .train()")
         # module.eval(): running statistics instead of batch statistics (forward only; the reference never trains in eval mode)
         L.check(L.lib().mfvi_plan_set_bn_eval(plan.handle, L.ptr(self._running) if bn_eval else None))
         out = plan.forward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, sample)
@@ -390,14 +445,13 @@ class MeanFieldVI(nn.Module):
             if len(mom) != 1 or None in mom:
                 raise NotImplementedError("BatchNorm2d momentum must be one number for all layers (the skip() nets use the default 0.1)")
             L.check(L.lib().mfvi_plan_bn_update_running(plan.handle, L.ptr(plan.workspace), self.n_samples, float(mom.pop()), L.ptr(self._running), L.stream_ptr()))
-            for b in self._bn:
-                b.num_batches_tracked += self.n_samples
+            torch._foreach_add_([b.num_batches_tracked for b in self._bn], self.n_samples)      # one launch for the ~30 counters
         self._token += 1
         if sample or dropping:
             self._step += 1                  # fresh eps / dropout masks for every call, like randn_like in VIModule.rsample
         return out, (self._token, plan, x3, step, sample)
 
-    def _hip_backward(self, token, dout, want_dz):
+    def _hip_backward(self, token, dout, want_dz, flat=False):
         tok, plan, x3, step, sample = token
         if tok != self._token:
             raise RuntimeError("backward through a MeanFieldVI forward that is no longer the latest one: the activations live in one "
@@ -407,6 +461,10 @@ class MeanFieldVI(nn.Module):
         n = self.n_vi
         dz = torch.empty((self.n_samples,) + tuple(x3.shape), device=self.device) if want_dz else None
         plan.backward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, dout, g[:n], g[n:2 * n], g[2 * n:], sample, dz=dz)
+        if flat:
+            if want_dz:
+                dz = dz.sum(0, keepdim=True) if dz.shape[0] > 1 else dz
+            return g[:2 * n + self.n_bn], dz
         grads = []
         for m in self._vi:
             nw = m.W_mu.numel()
@@ -428,14 +486,16 @@ class MeanFieldVI(nn.Module):
                                 L.ptr(acc), L.stream_ptr()))
         return acc.float()                                   # FloatTensor of shape [1], as the reference returns
 
-    def _hip_kl_backward(self, lo, hi, prior_mu, prior_sigma, gout):
+    def _hip_kl_backward(self, lo, hi, prior_mu, prior_sigma, gout, flat=False):
         mu, rho, _ = self._blocks()
         n = self.n_vi
-        g = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
+        g = torch.zeros(2 * n + (self.n_bn if flat else 0), dtype=torch.float32, device=self.device)
         scale = float(gout.reshape(-1)[0])
         L.check(L.lib().mfvi_kl_backward(L.ptr(mu[lo:hi]), L.ptr(rho[lo:hi]), hi - lo, prior_mu,
                                          float(torch.tensor(prior_sigma, dtype=torch.float32)), scale, L.ptr(g[lo:hi]), L.ptr(g[n + lo:n + hi]),
                                          L.stream_ptr()))
+        if flat:
+            return g
         grads = []
         for m in self._vi:
             nw = m.W_mu.numel()

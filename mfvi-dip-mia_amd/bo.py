@@ -13,11 +13,9 @@ generated.  What follows restates those published models with plain torch (CPU, 
   candidates   <= 4 local maxima of the acquisition on the 100 x 100 grid (min distance 5, >= 0.1 * max) plus the global one, each refined
                with L-BFGS (strong Wolfe) through a sigmoid parametrisation of [0, 1]^2               :3649-3684
   loop         evaluate candidates (fan-out), drop NaNs, refit, propose; 20 rounds                    :3727-3880
-  scaling      DEVIATION: the reference's normalize_X / unnormalize_X (:3687-3706) apply the LOG bounds to the RAW values, so its
-               log-spaced grid lands in [1, 1.1]^2 of the unit square and, from the second round on, the proposals handed to the fits
-               are numbers in [logbound_lo, logbound_hi] (negative temperatures / variances; its own fig. 4 then plots log10 of them).
-               Here the same affine maps act on log10 of the hyper-parameters — what the logbounds, the logspace grid and the log10 plots
-               imply — and proposals are 10 ** unnormalize_X(...).
+  scaling      normalize_X / unnormalize_X (:3687-3706) work on log10 of the hyper-parameters: log10, then the affine map of the log
+               bounds onto [0, 1]; back: the inverse map, then 10 ** x.  The helpers below restate exactly that (the log10 / pow(10)
+               live inside them, as in the reference).
 """
 import itertools
 import math
@@ -184,19 +182,19 @@ def find_candidates(gp, X_, samples, acq_fn="ei", grid=100):
 
 
 def normalize_X(X_unnorm, x1_logbounds, x2_logbounds):
-    """:3687-3695: affine map of the box [lo, hi]^2 onto [0, 1]^2 (bo() applies it to log10 of the hyper-parameters, see the header)."""
-    X = X_unnorm.clone()
+    """:3687-3695: log10 of the hyper-parameters, then the affine map of the log-bounds box onto [0, 1]^2."""
+    X = X_unnorm.clone().log10()
     X[:, 0] -= x1_logbounds[0]; X[:, 0] /= (x1_logbounds[1] - x1_logbounds[0])
     X[:, 1] -= x2_logbounds[0]; X[:, 1] /= (x2_logbounds[1] - x2_logbounds[0])
     return X
 
 
 def unnormalize_X(X_norm, x1_logbounds, x2_logbounds):
-    """:3698-3706."""
+    """:3698-3706: the inverse map, then 10 ** x."""
     X = X_norm.clone()
     X[:, 0] *= (x1_logbounds[1] - x1_logbounds[0]); X[:, 0] += x1_logbounds[0]
     X[:, 1] *= (x2_logbounds[1] - x2_logbounds[0]); X[:, 1] += x2_logbounds[0]
-    return X
+    return 10.0 ** X
 
 
 def bo(bo_params, evaluate, n_rounds=20, gp_iters=2000, acq_fn="ei", verbose=True):
@@ -221,13 +219,13 @@ def bo(bo_params, evaluate, n_rounds=20, gp_iters=2000, acq_fn="ei", verbose=Tru
         X += [c for c, _ in got]; Y += [y for _, y in got]
         if not X:
             raise RuntimeError("bo: every fit of the first round failed")
-        X_train = normalize_X(torch.log10(torch.tensor(np.array(X), dtype=torch.float64)), lb1, lb2)
+        X_train = normalize_X(torch.tensor(np.array(X), dtype=torch.float64), lb1, lb2)
         Y_train = torch.tensor(np.array(Y), dtype=torch.float64)
         gp = train_gp(X_train, Y_train, gp_iters, verbose=False)
-        X_test = normalize_X(torch.log10(X_), lb1, lb2)
+        X_test = normalize_X(X_, lb1, lb2)
         cands, exp_imp, _ = find_candidates(gp, X_test, X_train, acq_fn)
         cands = torch.unique(torch.cat(cands).cpu(), dim=0)
-        candidates = [tuple(map(float, c)) for c in (10.0 ** unnormalize_X(cands, lb1, lb2)).numpy()]
+        candidates = [tuple(map(float, c)) for c in unnormalize_X(cands, lb1, lb2).numpy()]
         if verbose:
             print("round %d: best %.4f at %s; next %s" % (rnd, max(Y), X[int(np.argmax(Y))], candidates))
     return X, Y, candidates

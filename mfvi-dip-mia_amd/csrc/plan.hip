@@ -591,20 +591,23 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
             }
         } else if (o.d.type == MFVI_OP_CONV) {
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
-            if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); return -1; }
+            if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); if (plan->side) (void)hipStreamSynchronize(plan->side); return -1; }
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
             TView a; if (o.d.in0 >= 0) a = c.view(o.d.in0);
             rc = launch_concat_up_fwd(o.d.in0 >= 0 ? &a : nullptr, c.view(o.d.in1), od, o.d.up_mode == MFVI_UP_NEAREST, n_samples, st);
         }
-        if (rc) { mfvi_tl_stop_event = nullptr; if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc)); return rc; }
+        if (rc) {      // forked skip-branch work may still be writing activations / BN statistics: join it before handing the buffers back
+            mfvi_tl_stop_event = nullptr; if (rc > 0) set_error("forward: op %d launch failed: %s", (int)i, hipGetErrorString((hipError_t)rc));
+            if (plan->side) (void)hipStreamSynchronize(plan->side);
+            return rc; }
         }
         const bool consumed = armed && mfvi_tl_stop_event == nullptr;      // the event went out on the launch's packet
         mfvi_tl_stop_event = nullptr;
         if (stc != st) {           // forked: its completion event, waited for in front of the consumer
             if (!consumed) {
                 const hipError_t e = hipEventRecord(ej, stc);
-                if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); return (int)e; }
+                if (e != hipSuccess) { set_error("forward: fork failed: %s", hipGetErrorString(e)); if (plan->side) (void)hipStreamSynchronize(plan->side); return (int)e; }
             }
             join_at[y.consumers.front()] = ej_idx;
         } else if (pre_for == i + 1) pre_done = consumed;

@@ -159,13 +159,21 @@ class ElboEngine:
             self.plan.forward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.sample_weights, self.out)
             self._loss_and_dout(n)
             if after_forward is not None and c0 + n >= self.K_local:
-                after_forward()        # self.out of the last launch is final in stream order here: work that only reads it can overlap the backward pass
+                after_forward(n)       # self.out holds the n samples of the LAST launch, final in stream order here: work that only reads it can overlap the backward pass
             self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn,
                                self.sample_weights)
         if self.world > 1:
             # the single exchange of the K-sharded step: grads (+ the NLL scalar) summed over ranks
             self.grads[self.n_params] = self.acc[0].float()
-            allreduce_sum_(self.grads, self.pg)
+            if self.grads.is_cuda:      # HIP events around the collective (bench.py's allreduce_ms): recorded on the stream it is enqueued on
+                ev = self._ar_events = getattr(self, "_ar_events", [])
+                if len(ev) >= 64:
+                    ev.pop(0)
+                a_, b_ = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                a_.record(); allreduce_sum_(self.grads, self.pg); b_.record()
+                ev.append((a_, b_))
+            else:
+                allreduce_sum_(self.grads, self.pg)
         if with_kl:
             # KL and its gradient are deterministic: every rank computes them redundantly (no communication)
             mu, rho = self.mu, self.rho
@@ -174,6 +182,15 @@ class ElboEngine:
             L.check(lib.mfvi_kl(L.ptr(mu), L.ptr(rho), self.n_vi, 0.0, self.prior_sigma, L.ptr(self.acc[1:]), sp))
             L.check(lib.mfvi_kl_backward(L.ptr(mu), L.ptr(rho), self.n_vi, 0.0, self.prior_sigma, self.temp,
                                          L.ptr(self.dmu), L.ptr(self.drho), sp))
+
+    def allreduce_ms(self):
+        """Mean duration (ms) of the gradient all-reduce over the last <= 64 iterations, from events on the stream it was enqueued on
+        (synchronises); None on a single rank."""
+        ev = getattr(self, "_ar_events", [])
+        if not ev:
+            return None
+        self.torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def params_f32(self):
         """(mu, rho, bn) as float32 tensors: views of the parameter buffer, or the expansion of the bf16 blocks (mfvi_bf16_to_f32)."""
@@ -187,7 +204,7 @@ class ElboEngine:
 
     def step(self, after_forward=None):
         """One ELBO iteration: K forwards + NLL + backward + (all-reduce), then KL + its gradient + Adam in one fused launch
-        (identical on every rank: no communication).  after_forward: optional callable run once the last forward + data term of the
+        (identical on every rank: no communication).  after_forward: optional callable f(n) run once the last forward (n samples in self.out) + data term of the
         iteration are enqueued (the runners start their per-iteration bookkeeping there, on a second stream beside the backward pass)."""
         lib, sp = L.lib(), L.stream_ptr()
         self.grad_only(self.t, with_kl=False, after_forward=after_forward)

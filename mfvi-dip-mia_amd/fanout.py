@@ -36,12 +36,17 @@ def _resolve(fn):
 def _worker(device, jobs, fn, run_params, queue):
     """Body of one per-device process.  jobs: [(index, job kwargs)]; fn: 'module:function' (or a picklable callable) returning either
     the PSNR or a dict with key 'psnr' (the runners of mfvi_dip_mia_amd.runner)."""
+    dev = str(device)
     try:
-        dev = str(device)
-        if dev.startswith("cuda"):
-            import torch                                   # fresh interpreter: the first GPU call of this process picks its device
-            torch.cuda.set_device(int(dev.split(":")[1]) if ":" in dev else 0)
-        f = _resolve(fn)
+        try:
+            if dev.startswith("cuda"):
+                import torch                               # fresh interpreter: the first GPU call of this process picks its device
+                torch.cuda.set_device(int(dev.split(":")[1]) if ":" in dev else 0)
+            f = _resolve(fn)
+        except Exception as e:                             # a device that is not on the box, an import error: every job of this worker
+            for idx, _ in jobs:                            # is reported with the reason instead of a bare 'worker died'
+                queue.put((idx, dev, os.getpid(), float("nan"), "worker setup failed: %s: %s" % (type(e).__name__, e)))
+            return
         for idx, kw in jobs:
             try:
                 res = f(**kw, **run_params)
@@ -50,39 +55,62 @@ def _worker(device, jobs, fn, run_params, queue):
             except Exception as e:                         # one failed fit must not take the other candidates of this device down
                 queue.put((idx, dev, os.getpid(), float("nan"), "%s: %s" % (type(e).__name__, e)))
     finally:
-        queue.put(None)                                    # this worker is done
+        queue.put(("done", dev))                           # this worker is done (never sent by a process that dies hard)
 
 
-def run_jobs(jobs, devices, fn, run_params=None, start_method="spawn"):
+def run_jobs(jobs, devices, fn, run_params=None, start_method="spawn", poll_seconds=0.5):
     """Run fn(**job, **run_params) for every job, job i on devices[i % len(devices)], one fresh process per device.
     Returns (results, dropped): results = [(job index, job, psnr)] with NaN results removed (bayesian_optimization.py:3777-3781),
-    sorted by job index; dropped = [(job index, job, error message or 'nan')]."""
+    sorted by job index; dropped = [(job index, job, error message or 'nan')].
+
+    A worker that dies without running its `finally` (GPU fault, abort, SIGSEGV, the OOM killer) sends no sentinel: the gather polls the
+    queue with a timeout and checks the processes, so such a worker counts as finished and the jobs it had not reported are dropped with
+    its exit code — the reference joins its children the same way (bayesian_optimization.py:3764-3775)."""
     import multiprocessing as mp
+    import queue as queue_mod
     run_params = dict(run_params or {})
     devices = [str(d) for d in devices]
     per = assign(len(jobs), devices)
     ctx = mp.get_context(start_method)
     queue = ctx.Queue()
-    procs = []
+    procs = {}
     for d in devices:
         if not per[d]:
             continue
         p = ctx.Process(target=_worker, args=(d, [(i, jobs[i]) for i in per[d]], fn, run_params, queue))
         p.start()
-        procs.append(p)
-    got, done = {}, 0
-    while done < len(procs):
-        item = queue.get()
-        if item is None:
-            done += 1
+        procs[d] = p
+    got, finished, died = {}, set(), {}
+    while len(finished) < len(procs):
+        try:
+            item = queue.get(timeout=poll_seconds)
+        except queue_mod.Empty:
+            for d, p in procs.items():
+                if d not in finished and not p.is_alive():
+                    # drain what the dead worker managed to send before deciding which of its jobs are lost
+                    try:
+                        while True:
+                            late = queue.get(timeout=0.05)
+                            if late[0] == "done":
+                                finished.add(late[1])
+                            else:
+                                got[late[0]] = late
+                    except queue_mod.Empty:
+                        pass
+                    if d not in finished:
+                        finished.add(d); died[d] = p.exitcode
+            continue
+        if item[0] == "done":
+            finished.add(item[1])
             continue
         got[item[0]] = item
-    for p in procs:
+    for p in procs.values():
         p.join()
     results, dropped = [], []
     for i in range(len(jobs)):
         if i not in got:
-            dropped.append((i, jobs[i], "worker died")); continue
+            d = devices[i % len(devices)]
+            dropped.append((i, jobs[i], "worker on %s died (exit code %s)" % (d, died.get(d, procs[d].exitcode)))); continue
         _, dev, pid, psnr, err = got[i]
         if err is not None or math.isnan(psnr):
             dropped.append((i, jobs[i], err or "nan"))

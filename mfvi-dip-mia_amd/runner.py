@@ -68,8 +68,11 @@ class _AsyncBook:
     results) orders the caller's stream behind it before `eng.out` is written again."""
     _side = None; _done = None
 
-    def hook(self, eng, i, n):
-        def run():
+    def hook(self, eng, i, n=None):
+        """-> the callable for eng.step(after_forward=...).  The engine passes the sample count of its LAST launch (eng.out holds only
+        those; with K_local not a multiple of the launch size the last launch is partial), which overrides `n`."""
+        def run(n_last=None):
+            n_ = n if n_last is None else n_last
             t = self.t
             if self._side is None:
                 self._side = t.cuda.Stream(); self._done = t.cuda.Event()
@@ -77,7 +80,7 @@ class _AsyncBook:
             ready = t.cuda.Event(); ready.record(main)
             with t.cuda.stream(self._side):
                 self._side.wait_event(ready)
-                self.iteration(eng, i, n)
+                self.iteration(eng, i, n_)
                 self._done.record(self._side)
         self.wait()          # the previous iteration's bookkeeping has read eng.out before this iteration's forward overwrites it
         return run

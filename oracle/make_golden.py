@@ -268,6 +268,55 @@ def golden_traj(name, onet, seed, K, steps, lr=1e-3):
     print(name, "loss", losses)
 
 
+def golden_fitcurve(name, size, seed, steps, every=10, lr=1e-3):
+    """Fit QUALITY, not one step: the reference's denoising loop (bayesian_optimization.py:1356-1406 — MeanFieldVI + skip + gaussian_nll +
+    temp * net.kl() + torch.optim.AdamW, K = 1, exp_weight 0.99 smoothing, its own peak_signal_noise_ratio) for `steps` iterations on the
+    full 26-layer net at size x size, with eps and the input perturbation injected from the build's RNG spec and the parameters the
+    engine starts from (O.init_params: mu ~ N(0, 0.1), rho ~ N(-3, 0.1), gamma 1, beta 0).  Stored every `every` iterations: ELBO, NLL,
+    KL, PSNR(gt, out), PSNR(gt, out_avg) — once run in float32 (what the reference does) and once in float64 (the reference code on
+    double tensors): the gap between the two curves is the band inside which any float32 implementation can be expected to land."""
+    temp = DEN["temp"]; prior_raw = float(np.sqrt(temp) * DEN["sigma"])
+    onet = O.make_net(size, size)
+    conv, bn, n_vi, n_bnp = O.net_table(onet)
+    H = W = size
+    z0 = (0.1 * O.uniform_fill(seed, 0, 0, 0, onet.input_depth * H * W)).reshape(1, onet.input_depth, H, W)
+    gt_np = O.phantom(H, W, seed); noisy_np = O.noisy(gt_np, 0.1, seed)
+    res = {}
+    for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+        mu, rho, bnp = O.init_params(onet, seed)
+        net = build_ref_net(onet, prior_raw); load_flat(net, mu, rho, bnp, conv, bn)
+        net = net.to(dt)
+        layers = vi_layers(net)
+        tgt = torch.from_numpy(noisy_np)[None, None].to(dt); gt = torch.from_numpy(gt_np)[None, None].to(dt)
+        opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=0)
+        out_avg = None
+        rows = []
+        with EpsInjector() as inj:
+            for it in range(steps):
+                opt.zero_grad()
+                zn = O.normal_fill(seed, 1, 0, 0, it, z0.size).reshape(z0.shape)
+                zt = torch.from_numpy(z0 + 0.1 * zn).to(dt)
+                inj.load(layers, seed, it, 0)
+                inj.queue[:] = [e.to(dt) for e in inj.queue]
+                out = net(zt)
+                nll = R["bu"].gaussian_nll(out[:, :1], out[:, 1:], tgt)
+                kl = net.kl()
+                loss = nll + temp * kl
+                loss.backward(); opt.step()
+                with torch.no_grad():
+                    out[:, 1:] = torch.exp(-out[:, 1:])
+                out_avg = out.detach() if out_avg is None else out_avg * 0.99 + out.detach() * 0.01
+                if it % every == 0 or it == steps - 1:
+                    with torch.no_grad():
+                        psnr_gt = R["cu"].peak_signal_noise_ratio(gt, out.detach()[:, :1].clip(0, 1))
+                        psnr_sm = R["cu"].peak_signal_noise_ratio(gt, out_avg.detach()[:, :1].clip(0, 1))
+                    rows.append((it, float(loss), float(nll), float(kl), psnr_gt, psnr_sm))
+        res["curve" + tag] = np.array(rows, np.float64)
+        print(name, tag or "_f32", "last:", rows[-1])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, steps=steps, every=every, lr=lr, temp=temp, sigma=DEN["sigma"],
+                        prior_sigma=np.float32(prior_raw + 1e-6), size=size, columns=np.array(["it", "elbo", "nll", "kl", "psnr_gt", "psnr_gt_sm"]), **res)
+
+
 def golden_layers():
     """Single Conv2dRT (ReflectionPad2d + conv, models/common.py:100-135) fwd/bwd with injected eps."""
     from models.common import conv as ref_conv
@@ -732,6 +781,10 @@ if __name__ == "__main__":
         golden_bookkeeping(); sys.exit(0)
     if "--inp-dip" in sys.argv:
         golden_inp_dip_loss(); sys.exit(0)
+    if "--fitcurve" in sys.argv:          # minutes of CPU: the reference's loop for 400 / 100 iterations, float32 and float64
+        golden_fitcurve("fitcurve_den_64", 64, seed=1, steps=400)
+        golden_fitcurve("fitcurve_den_128", 128, seed=1, steps=100)
+        sys.exit(0)
     if "--siblings" in sys.argv:
         golden_siblings(); sys.exit(0)
     if "--inpainting" in sys.argv:       # only the inpainting fixtures (the others are unchanged)

@@ -179,6 +179,26 @@ def test_independent_fit_fanout_with_stub_worker():
     assert os.getpid() not in {next(iter(v)) for v in pids.values()}
 
 
+def test_fanout_survives_a_worker_that_dies_hard():
+    """A worker process that exits without running its `finally` (os._exit here; a GPU fault, SIGSEGV or the OOM killer in production)
+    sends no sentinel: run_jobs must return — the jobs that worker had not reported are dropped with its exit code, the jobs it had
+    finished and those of the other workers are kept (the reference joins its children: bayesian_optimization.py:3764-3781).  A worker
+    whose set-up fails (a device that is not on the box) reports the reason for each of its jobs."""
+    import time
+    from mfvi_dip_mia_amd import fanout
+    # device cpu:0 gets jobs 0, 2, 4 (temps 1, 9, 2): it finishes job 0, dies inside job 2 and never reaches job 4; cpu:1 gets 1, 3, 5
+    jobs = [dict(temp=t, sigma=0.5) for t in (1.0, 4.0, 9.0, 6.0, 2.0, 8.0)]
+    t0 = time.time()
+    results, dropped = fanout.run_jobs(jobs, ["cpu:0", "cpu:1"], "fanout_stub:fit", dict(scale=1.0), poll_seconds=0.2)
+    assert time.time() - t0 < 60
+    assert [i for i, _, _ in results] == [0, 1, 3, 5]
+    assert sorted(i for i, _, _ in dropped) == [2, 4]
+    assert all("died" in why and "exit code 3" in why for _, _, why in dropped)
+    # set-up failure: torch.cuda.set_device on a box without that GPU (or without any): reported per job, nothing hangs
+    results, dropped = fanout.run_jobs(jobs[:2], ["cuda:63"], "fanout_stub:fit", dict(scale=1.0), poll_seconds=0.2)
+    assert results == [] and len(dropped) == 2 and all("worker setup failed" in why for _, _, why in dropped)
+
+
 def test_runner_config_devices_and_jobs(tmp_path):
     """load_config keeps the reference's run_params.devices (eval_result.py:21-22) for the fan-out; the CLI's job list is images x candidates."""
     import json
@@ -265,7 +285,7 @@ def test_gp_outer_loop_restatement():
     for c in cands:
         assert c.shape == (1, 2) and (c >= 0).all() and (c <= 1).all()
     Xn = B.normalize_X(torch.tensor([[1e-3, 1e-5]], dtype=torch.float64), [-4.0, -2.0], [-6.0, -4.0])
-    assert torch.allclose(Xn, torch.tensor([[(1e-3 + 4.0) / 2.0, (1e-5 + 6.0) / 2.0]], dtype=torch.float64))
+    assert torch.allclose(Xn, torch.tensor([[(-3.0 + 4.0) / 2.0, (-5.0 + 6.0) / 2.0]], dtype=torch.float64))       # log10 first (bayesian_optimization.py:3688)
     assert torch.allclose(B.unnormalize_X(Xn, [-4.0, -2.0], [-6.0, -4.0]), torch.tensor([[1e-3, 1e-5]], dtype=torch.float64))
     # the loop on a synthetic objective; one candidate fails (NaN) in every round and must be dropped
     calls = []
