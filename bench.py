@@ -93,23 +93,29 @@ REFERENCE_CPU_PROBE = dict(value=5.61, unit="ELBO-iterations/s (K = 1 MC pass ea
                            source="BASELINE.md section 3 (survey probe in the build container, not measured by this run)")
 
 
-def lib_sha256():
+def csrc_sha256():
+    """sha256 over the kernel sources the running library is built from (csrc/*.hip, csrc/*.h, include/mfvi_hip.h, sorted by name).
+    hipcc's output is not byte-reproducible (two builds of one source differ), so the SOURCES identify a build: __graft_entry__.build()
+    recompiles them in place, and mfvi-dip-mia_amd/_build.py rebuilds whenever one of them is newer than the .so."""
+    import glob
     import hashlib
     from mfvi_dip_mia_amd import _lib as L
+    d = os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "csrc")
+    files = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))) + [os.path.join(ROOT, "include", "mfvi_hip.h")]
     h = hashlib.sha256()
-    with open(L.LIB_PATH, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()
 
 
 def traffic_lookup(key):
-    """HBM bytes per launch of a kernel from the separate rocprofv3 --pmc passes (profiles/traffic.json), or None when the library that
-    produced those counters is not the one running now (the file carries the sha256 of its libmfvi_hip.so)."""
+    """HBM bytes per launch of a kernel from the separate rocprofv3 --pmc passes (profiles/traffic.json), or None when the kernels that
+    produced those counters are not the ones running now: the file carries the sha256 of the kernel sources it was measured on, and
+    a library set with MFVI_LIB_PATH (an experimental build) never matches."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(tfile))
-        if t.get("lib_sha256") != lib_sha256():
+        if os.environ.get("MFVI_LIB_PATH") or t.get("csrc_sha256") != csrc_sha256():
             return None
         return t["entries"].get(key)
     except Exception:
