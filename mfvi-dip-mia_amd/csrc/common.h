@@ -376,6 +376,10 @@ constexpr int SAMPLE_QUADS = 256;       // weight quads per block of the samplin
 struct BwwPart { float* base; long long stride; int max_strips; };
 int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int n_samples,
                                 hipStream_t st);
+// 3x3 stride-1 layers on maps whose width is a multiple of 64, on the bf16 matrix cores with three-way split operands (conv_bww_x6.hip):
+// cof = 16-channel output fragments per block (1 / 2), target = block-count target; same slabs as launch_conv_bwd_weight_mfma
+int launch_conv_bwd_weight_x6(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int cof, int target,
+                              int n_samples, hipStream_t st);
 struct GradFinEntry { long long w_off, b_off, part_off, stride; int n_w, n_b, strips, layer_id, first_block, pad; };
 // wsamp (optional): the sampled-weight slab of this pass, sample k at wsamp + k*wstride; then eps_k*softplus(rho) is read as W_k - mu
 int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const void* rho, RngKey key,

@@ -665,7 +665,8 @@ int env_tune_w()
 }  // namespace
 
 // Tiling (ConvGeom::tune[2], MFVI_TUNE_W=nb,w,target/256): nb | w << 8 | (target blocks / 256) << 16 with w = 4 (4 waves),
-// 8 (8 waves), 9 (8 waves, producer/consumer specialised) or 10 (fragment-split variant, nb = 2: 3x3 stride 1, full-width tiles); 0 = heuristic.
+// 8 (8 waves), 9 (8 waves, producer/consumer specialised), 10 (fragment-split variant, nb = 2: 3x3 stride 1, full-width tiles) or
+// 11 (bf16x6 kernel of conv_bww_x6.hip, nb = 16-channel output fragments per block: 3x3 stride 1 on maps whose width is a multiple of 64); 0 = heuristic.
 int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int n_samples,
                                 hipStream_t st)
 {
@@ -683,6 +684,7 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
     if (!forced && !vec_ok) cfg = (cfg & ~0xff00) | (4 << 8);      // heuristic falls back to the 4-wave variant
     const int nb = cfg & 255, wfield = (cfg >> 8) & 255, target = ((cfg >> 16) & 255) * 256;
     const bool spec = wfield == 9;
+    if (wfield == 11) return launch_conv_bwd_weight_x6(in, gy, g, part, strips_used, nb, target, n_samples, st);      // bf16x6 kernel (conv_bww_x6.hip), nb = output fragments per block
     if (wfield == 10) {
         // fragment-split variant: 3x3 stride 1, full-width tiles, aligned float4 staging, input-channel groups of 32 with a 4-channel remainder
         // riding in the last one (Cin = 16n or 16n + 4)
