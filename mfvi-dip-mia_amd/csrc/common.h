@@ -362,6 +362,13 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
 int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st);
 int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse);
 int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not served / disabled (MFVI_RP=0)
+// Forward of the 3x3 stride-1 layers with 32 n (+ 4) input channels on maps whose width is a multiple of 64, on the bf16 matrix cores with
+// three-way split operands (conv_x6.hip).  tune = mf | sr << 8 (output fragments per block, output rows per block).  Needs a scratch region
+// of x6_fwd_scratch_floats() floats for the split weight pieces: the plan hands it over in mfvi_tl_x6w around the launch (nullptr: -2).
+#define MFVI_TUNE_X6 (1 << 25)
+extern thread_local float* mfvi_tl_x6w;
+long long x6_fwd_scratch_floats(const ConvGeom& g, int n_samples);
+int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st);
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
 // bf16: mu / rho point to bf16_t arrays; sample = 0 writes W = mu (RTLayer's eval branch) — callers then launch it for ONE sample

@@ -40,6 +40,7 @@ struct OpInfo {
     long long scratch2_off = -1, s2_off = -1;  // LRT: padded scratch of the variance convolution's input gradient; s2 = conv(v^2, sigma^2) kept for the backward
     long long part_off = -1, part_stride = 0;  // floats: partial-dW slabs of the MFMA backward-weight kernel [strip][sample][stride]
     int max_strips = 0;
+    long long x6w_off = -1;                    // floats: split weight pieces of the bf16x6 forward (conv_x6.hip), -1: shape not served
 };
 
 inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
@@ -251,6 +252,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
             const long long ms = (4LL << 20) / (o.part_stride * p.max_samples);
             o.max_strips = (int)(ms < 1 ? 1 : (ms > 64 ? 64 : ms));
             o.part_off = take(o.part_stride * p.max_samples * o.max_strips);
+            if (o.d.type == MFVI_OP_CONV) { const long long xf = x6_fwd_scratch_floats(o.g, p.max_samples); if (xf > 0) o.x6w_off = take(xf); }
         }
     p.total_bytes = p.float_base + fo * (long long)sizeof(float);
     if (n_conv) {
@@ -590,7 +592,9 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
                 if (!rc) rc = launch_lrt_combine(oa.data, os.data, y.numel, y.d.C, (long long)y.d.H * y.d.W, key, o.g.layer_id, od, n_samples, st);
             }
         } else if (o.d.type == MFVI_OP_CONV) {
+            mfvi_tl_x6w = (presample && o.x6w_off >= 0) ? c.farena() + o.x6w_off : nullptr;
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
+            mfvi_tl_x6w = nullptr;
             if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); if (plan->side) (void)hipStreamSynchronize(plan->side); return -1; }
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
@@ -965,7 +969,12 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
             if (which == 1 && o.d.in0 == plan->input) continue;
             int strips_used = 0;
             auto launch = [&]() {
-                if (which == 0) return launch_conv_fwd_mfma(xin, o.g, c.wsamp(), plan->n_vi, od, n_samples, st);
+                if (which == 0) {
+                    mfvi_tl_x6w = o.x6w_off >= 0 ? c.farena() + o.x6w_off : nullptr;
+                    const int r0 = launch_conv_fwd_mfma(xin, o.g, c.wsamp(), plan->n_vi, od, n_samples, st);
+                    mfvi_tl_x6w = nullptr;
+                    return r0;
+                }
                 if (which == 1) {
                     const TensorInfo& x = plan->t[o.d.in0];
                     if ((o.g.ks == 1 || (o.g.ks == 3 && o.g.stride == 1 && fold_fusion3_on())) && x.consumers.size() == 1 && fold_fusion_on() && o.d.in0 != plan->input) {
@@ -991,6 +1000,8 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                 if (o.g.ks == 3 && o.g.stride == 1 && (o.g.W & 63) == 0 && rp_default_tune(o.g, which, n_samples))
                     for (int mf : {1, 2, 4}) for (int r : {1, 2, 4}) for (int rem = 0; rem <= ((which == 1 && (o.g.Cin & 15) == 4) ? 1 : 0); ++rem)
                         for (int T = 1; T <= 8; T *= 2) cands.push_back(mf | r << 8 | rem << 12 | T << 16 | MFVI_TUNE_RP);
+                // bf16x6 forward (conv_x6.hip): output fragments per block, 8 output rows per block
+                if (which == 0 && o.x6w_off >= 0) for (int mf : {1, 2}) for (int T = 1; T <= 16; T *= 2) cands.push_back(mf | 8 << 8 | T << 16 | MFVI_TUNE_X6);
             }
             else {
                 for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16);

@@ -91,6 +91,22 @@ __global__ void rate(float* out, int iters, unsigned seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)(f0 ^ f1);
 }
 
+// legacy K = 16 shape (4 bf16 per lane): candidate for the 4-channel remainder groups
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ void rate16(float* out, int iters, unsigned seed)
+{
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    s16x4 a = {(short)0x3f80, (short)(0x3f80 + (threadIdx.x & 3)), (short)0x3f80, (short)0x3f81}, b = {(short)0x3f80, (short)0x3f82, (short)(0x3f80 + (seed & 1)), (short)0x3f80};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0; for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F> float timeit(F f)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -133,6 +149,8 @@ int main()
         report("16x16x32 bf16, 21 acc", timeit([&] { hipLaunchKernelGGL((rate<21, 0>), dim3(blocks), dim3(threads), 0, 0, out, iters, 7u); }), 21);
         report("  + 1 alignbit per MFMA", timeit([&] { hipLaunchKernelGGL((rate<21, 1>), dim3(blocks), dim3(threads), 0, 0, out, iters, 7u); }), 21);
         report("  + 2 alignbit per MFMA", timeit([&] { hipLaunchKernelGGL((rate<21, 2>), dim3(blocks), dim3(threads), 0, 0, out, iters, 7u); }), 21);
+        { const float ms = timeit([&] { hipLaunchKernelGGL((rate16<21>), dim3(blocks), dim3(threads), 0, 0, out, iters, 7u); });
+          printf("16x16x16 bf16_1k, 21 acc     %d waves/CU: %7.3f ms  (%.1f cycles/MFMA/SIMD @2.4GHz)\n", wpb, ms, ms * 1e-3 * 2.4e9 / (21.0 * iters * wpb / 4)); }
         report("  + 4 alignbit per MFMA", timeit([&] { hipLaunchKernelGGL((rate<21, 4>), dim3(blocks), dim3(threads), 0, 0, out, iters, 7u); }), 21);
     }
     return 0;
