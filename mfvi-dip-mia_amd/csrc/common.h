@@ -367,7 +367,12 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not 
 // of x6_fwd_scratch_floats() floats for the split weight pieces: the plan hands it over in mfvi_tl_x6w around the launch (nullptr: -2).
 #define MFVI_TUNE_X6 (1 << 25)
 extern thread_local float* mfvi_tl_x6w;
+extern thread_local bool mfvi_tl_x6w_ready;      // the pieces of this pass are already in the scratch (launch_x6_split_all)
 long long x6_fwd_scratch_floats(const ConvGeom& g, int n_samples);
+// one launch for all bf16x6 layers of a pass: dst_off = the layer's scratch offset (floats) in the arena, first_block = running block count
+struct X6SplitEntry { long long w_off, dst_off; int Cin, Cout, COp, ncg, rem, units, first_block, pad; };
+bool x6_split_entry(const ConvGeom& g, long long dst_off, X6SplitEntry* e);      // false: shape not served
+int launch_x6_split_all(const X6SplitEntry* table_dev, int n_entries, int n_blocks, const float* w, long long wstride, int n_k, float* arena, hipStream_t st);
 int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st);
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 thread_local float* mfvi_tl_x6w = nullptr;      // scratch of the op being launched (plan.hip), nullptr: bf16x6 forward not available
+thread_local bool mfvi_tl_x6w_ready = false;    // the scratch already holds this pass's pieces (launch_x6_split_all ran behind the weight draw)
 
 namespace {
 
@@ -76,6 +77,37 @@ __global__ void x6_split_weights_kernel(X6WArgs A)
         }
     }
     u32x4 h, m, l; split8(e, h, m, l);
+    u32x4* d = reinterpret_cast<u32x4*>(A.dst) + (long long)k * A.dstride_u4 + ((long long)row * 3 * A.COp + co) * 4 + oct;
+    d[0] = h; d[(long long)A.COp * 4] = m; d[(long long)A.COp * 8] = l;
+}
+
+// the same for every bf16x6 layer of a plan in ONE launch behind the weight draw (a launch per layer in front of its convolution put
+// ~10 us of dependent launch latency on the forward pass's critical path per layer)
+__global__ void x6_split_all_kernel(const X6SplitEntry* __restrict__ table, int n_entries, const float* w, long long wstride, float* arena)
+{
+    int e = 0;
+    while (e + 1 < n_entries && (int)blockIdx.x >= table[e + 1].first_block) ++e;
+    const X6SplitEntry E = table[e];
+    X6WArgs A;
+    A.w = w; A.wstride = wstride; A.dst = reinterpret_cast<unsigned*>(arena + E.dst_off); A.dstride_u4 = (long long)E.units * 3;
+    A.Cin = E.Cin; A.Cout = E.Cout; A.COp = E.COp; A.ncg = E.ncg; A.rem = E.rem; A.w_off = E.w_off; A.units = E.units;
+    const int u = ((int)blockIdx.x - E.first_block) * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (u >= A.units) return;
+    const int oct = u & 3, co = (u >> 2) % A.COp, row = (u >> 2) / A.COp;
+    const float* __restrict__ ww = A.w + (long long)k * A.wstride + A.w_off;
+    float e8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (co < A.Cout) {
+        if (row < A.ncg * 9) {
+            const int cg = row / 9, tap = row - cg * 9;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e8[j] = ww[((long long)co * A.Cin + cg * 32 + oct * 8 + j) * 9 + tap];
+        } else if (oct < 3) {
+            const int ky = row - A.ncg * 9;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e8[j] = ww[((long long)co * A.Cin + A.ncg * 32 + j) * 9 + ky * 3 + oct];
+        }
+    }
+    u32x4 h, m, l; split8(e8, h, m, l);
     u32x4* d = reinterpret_cast<u32x4*>(A.dst) + (long long)k * A.dstride_u4 + ((long long)row * 3 * A.COp + co) * 4 + oct;
     d[0] = h; d[(long long)A.COp * 4] = m; d[(long long)A.COp * 8] = l;
 }
@@ -355,7 +387,22 @@ int launch_one(X6FArgs& A, hipStream_t st)
 
 }  // namespace
 
-// bytes of split weights per sample
+bool x6_split_entry(const ConvGeom& g, long long dst_off, X6SplitEntry* e)
+{
+    if (x6_fwd_scratch_floats(g, 1) == 0) return false;
+    e->w_off = g.w_off; e->dst_off = dst_off; e->Cin = g.Cin; e->Cout = g.Cout; e->COp = (g.Cout + 31) / 32 * 32;
+    e->ncg = g.Cin / 32; e->rem = (g.Cin & 31) ? 1 : 0; e->units = (e->ncg * 9 + (e->rem ? 3 : 0)) * e->COp * 4; e->first_block = 0; e->pad = 0;
+    return true;
+}
+
+int launch_x6_split_all(const X6SplitEntry* table_dev, int n_entries, int n_blocks, const float* w, long long wstride, int n_k, float* arena, hipStream_t st)
+{
+    if (n_entries <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(x6_split_all_kernel, dim3(n_blocks, n_k), dim3(256), 0, st, table_dev, n_entries, w, wstride, arena);
+    return (int)hipGetLastError();
+}
+
+// floats of split weight pieces for n_samples samples (0: shape not served)
 long long x6_fwd_scratch_floats(const ConvGeom& g, int n_samples)
 {
     if (g.ks != 3 || g.stride != 1 || (g.W & 63) || g.Cin < 32 || ((g.Cin & 31) != 0 && (g.Cin & 31) != 4)) return 0;
@@ -383,7 +430,7 @@ int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long 
     X6WArgs WA{};
     WA.w = w; WA.wstride = wstride; WA.dst = reinterpret_cast<unsigned*>(scratch); WA.dstride_u4 = units * 3;
     WA.Cin = g.Cin; WA.Cout = g.Cout; WA.COp = COp; WA.ncg = ncg; WA.rem = rem; WA.w_off = g.w_off; WA.units = (int)units;
-    hipLaunchKernelGGL(x6_split_weights_kernel, dim3((unsigned)((units + 255) / 256), n_k), dim3(256), 0, st, WA);
+    if (!mfvi_tl_x6w_ready) hipLaunchKernelGGL(x6_split_weights_kernel, dim3((unsigned)((units + 255) / 256), n_k), dim3(256), 0, st, WA);
     X6FArgs A{};
     A.in = in; A.g = g; A.out = out; A.w = w; A.wstride = wstride;
     A.wsp = reinterpret_cast<const unsigned*>(scratch); A.wsp_stride_u4 = wstride ? units * 3 : 0;

@@ -59,6 +59,7 @@ struct mfvi_plan {
     BnGradEntry* table_dev = nullptr; int n_entries = 0, max_c = 1;
     SampleEntry* samp_dev = nullptr; int n_samp = 0, samp_blocks = 0;    // layers whose weights are drawn once per pass
     long long wsamp_off = -1;                  // floats: sampled weights [max_samples][n_vi]
+    X6SplitEntry* x6_dev = nullptr; std::vector<X6SplitEntry> x6_uploaded;      // table of the bf16x6 forward layers' weight split (conv_x6.hip)
     int param_dtype = MFVI_PARAM_F32;          // storage of mu / rho handed to forward / backward (MFVI_PARAM_BF16: bf16_t arrays)
     int n_generic = 0;                         // conv layers outside the sampling table (served by the generic fp32 kernels)
     long long p32_off = -1;                    // floats: [mu | rho] expanded to float32 for those kernels when mu / rho are bf16
@@ -415,6 +416,7 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     for (auto e : plan->free_events) (void)hipEventDestroy(e);
     if (plan->table_dev) (void)hipFree(plan->table_dev);
     if (plan->fin_dev) (void)hipFree(plan->fin_dev);
+    if (plan->x6_dev) (void)hipFree(plan->x6_dev);
     if (plan->samp_dev) (void)hipFree(plan->samp_dev);
     if (plan->drop_dev) (void)hipFree(plan->drop_dev);
     for (auto e : plan->fork_events) (void)hipEventDestroy(e);
@@ -520,6 +522,25 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         const int rc = launch_dropout_masks(plan->drop_dev, plan->n_drop, key, n_samples, c.farena(), st);
         if (rc) { set_error("forward: dropout mask launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
+    bool x6_ready = false;
+    if (presample) {      // weight pieces of the layers whose forward runs on the bf16x6 kernel: one launch behind the draw
+        std::vector<X6SplitEntry> tab; int nb = 0;
+        for (auto& o : plan->ops)
+            if (o.d.type == MFVI_OP_CONV && o.x6w_off >= 0 && (o.g.tune[0] & MFVI_TUNE_X6)) {
+                X6SplitEntry e; if (!x6_split_entry(o.g, o.x6w_off, &e)) continue;
+                e.first_block = nb; nb += (e.units + 255) / 256; tab.push_back(e);
+            }
+        if (!tab.empty()) {
+            hipError_t e = hipSuccess;
+            if (!plan->x6_dev) e = hipMalloc((void**)&plan->x6_dev, sizeof(X6SplitEntry) * plan->ops.size());
+            const bool same = tab.size() == plan->x6_uploaded.size() && memcmp(tab.data(), plan->x6_uploaded.data(), sizeof(X6SplitEntry) * tab.size()) == 0;
+            if (e == hipSuccess && !same) { e = hipMemcpyAsync(plan->x6_dev, tab.data(), sizeof(X6SplitEntry) * tab.size(), hipMemcpyHostToDevice, st); plan->x6_uploaded = tab; }
+            if (e != hipSuccess) { set_error("forward: weight-piece table setup failed: %s", hipGetErrorString(e)); return (int)e; }
+            const int rc = launch_x6_split_all(plan->x6_dev, (int)tab.size(), nb, c.wsamp(), sample_weights ? plan->n_vi : 0, sample_weights ? n_samples : 1, c.farena(), st);
+            if (rc) { set_error("forward: weight-piece launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+            x6_ready = true;
+        }
+    }
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = (presample && sample_weights) ? plan->n_vi : 0;
     // A skip-branch convolution (its only consumer is a later concat) on a map of up to MFVI_FWD_FORK pixels (default 128 x 128; 0 = never)
     // runs on the plan's side stream beside the down path of its scale and is joined in front of that concat: at those sizes both are
@@ -592,9 +613,9 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
                 if (!rc) rc = launch_lrt_combine(oa.data, os.data, y.numel, y.d.C, (long long)y.d.H * y.d.W, key, o.g.layer_id, od, n_samples, st);
             }
         } else if (o.d.type == MFVI_OP_CONV) {
-            mfvi_tl_x6w = (presample && o.x6w_off >= 0) ? c.farena() + o.x6w_off : nullptr;
+            mfvi_tl_x6w = (presample && o.x6w_off >= 0) ? c.farena() + o.x6w_off : nullptr; mfvi_tl_x6w_ready = x6_ready;
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
-            mfvi_tl_x6w = nullptr;
+            mfvi_tl_x6w = nullptr; mfvi_tl_x6w_ready = false;
             if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); if (plan->side) (void)hipStreamSynchronize(plan->side); return -1; }
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
