@@ -61,31 +61,38 @@ __device__ __forceinline__ void split4(const float (&e)[4], u32x2& h, u32x2& m, 
     l.x = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u); l.y = __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u);
 }
 
+// BW = band width in pixels: 64 (stage = 2 padded rows x 2 segments of 32 pixels) or 32 (maps 32 wide: stage = 4 padded rows x 1 segment)
+template <int BW>
 struct X6Cfg {
     static constexpr int CIB = 36;                       // input channels per block: two fragments + the 4-channel remainder
-    static constexpr int XROW = 160;                     // bytes of one (channel, row, piece): 80 bf16, image column c0 + t at element t + 8
-    static constexpr int XCH = 2 * 3 * XROW + 16;        // 976 = 16 * 61: the 16 channels of a ds_read_b128 lane group hit 64 distinct banks
+    static constexpr int R = 128 / BW;                   // padded x rows per stage (4 units of 32 pixels)
+    static constexpr int QX = BW / 4 + 2, QD = BW / 4;   // staged quads per x row (one halo quad each side) / dy row
+    static constexpr int XROW = (BW + 16) * 2;           // bytes of one (channel, row, piece): image column c0 + t at element t + 8
+    static constexpr int XCH = R * 3 * XROW + 16;        // 976 = 16 * 61 / 1168 = 16 * 73: the 16 channels of a ds_read_b128 lane group hit 64 distinct banks
     static constexpr int XBUF = CIB * XCH;
-    static constexpr int DROW = 128;                     // 64 bf16
+    static constexpr int DROW = BW * 2;
     static constexpr int DSLOT = 3 * DROW;
-    static constexpr int DCH = 6 * DSLOT + 16;           // 2320 = 16 * 145
+    static constexpr int NSLOT = 2 * R + 2;              // dy ring: rows i - 2 .. i + R - 1 in use, R being written
+    static constexpr int DCH = NSLOT * DSLOT + 16;       // 2320 = 16 * 145 / 1936 = 16 * 121
     static constexpr int ROWP = CIB * 9 + 2;             // epilogue: floats per output channel row
+    static_assert((XCH / 16) % 2 == 1 && (DCH / 16) % 2 == 1, "plane pitches");
 };
 
 struct X6Args {
     TView in; GView gy; ConvGeom g;
     float* part; long long part_stride;
-    int bands, rps;                                      // 64-pixel bands per row; padded rows per strip (even)
+    int bands, rps;                                      // bands per row; padded rows per strip (a multiple of the stage's rows)
     int ci_groups, nx, ny, nz;
 };
 
 struct X6Bwd { float mean, qc, c1, k2; };                // dy = (y - mean) * qc + (ga * c1 + k2)   (conv_rp.hip's RpBwd)
 
-template <int COF>
+template <int COF, int BW>
 __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
 {
-    using C = X6Cfg;
+    using C = X6Cfg<BW>;
     constexpr int CIB = C::CIB, XCH = C::XCH, XBUF = C::XBUF, DCH = C::DCH, DSLOT = C::DSLOT, ROWP = C::ROWP;
+    constexpr int R = C::R, QX = C::QX, QD = C::QD, NSLOT = C::NSLOT, XI = R * QX;
     constexpr int COB = 16 * COF, NSL = 4 / COF;         // output channels per block, pixel slices
     extern __shared__ __align__(16) char lds[];          // [2][CIB][XCH] x pieces | [COB][DCH] dy ring; the epilogue's [NSL][COB][ROWP] floats over both
     __shared__ ChanFwd s_chx[CIB];
@@ -108,9 +115,10 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
     const int nfull = cit >> 4; const bool x4 = (cit & 15) != 0;
     const bool do_bias = (ci0 == 0) && (g.b_off >= 0);
     const int band = bx % A.bands, strip = bx / A.bands;
-    const int c0 = band * 64;
-    const int i0 = strip * A.rps, i1 = min(H + 2, i0 + A.rps);             // padded x rows of this block
-    const int nst = (i1 - i0) >> 1;                                         // stages (launcher: every strip holds >= 1)
+    const int c0 = band * BW;
+    // padded x rows of this block; rows past H + 1 (R = 4: H + 2 is not a multiple of it) meet dy rows >= H only, which are staged as zeros
+    const int i0 = strip * A.rps, i1 = min((H + 2 + R - 1) / R * R, i0 + A.rps);
+    const int nst = (i1 - i0) / R;                                          // stages (launcher: every strip holds >= 1)
 
     const float* __restrict__ xin = A.in.data + (long long)k * A.in.sstride;
     const float* __restrict__ gap = A.gy.ga + (long long)k * A.gy.gstride;
@@ -134,76 +142,81 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
     if (producer) {
         // ======================= staging waves =======================
         __builtin_amdgcn_s_setprio(2);
-        // x items: (channel c, row r of the stage, quad v = 0..17 at image columns c0 - 4 + 4 v), 36 per channel; fixed per thread
-        constexpr int NXJ = (CIB * 36 + 255) / 256;       // 6
-        constexpr int NGJ = (COB * 32) / 256;             // 2 COF: (channel, row, quad v = 0..15 at columns c0 + 4 v)
-        int xgo[NXJ]; int xlo[NXJ]; unsigned xr = 0, xfl = 0, xok = 0;
-        const int n_xi = cit * 36;
+        // x items: (channel c, row r of the stage, quad v = 0 .. QX - 1 at image columns c0 - 4 + 4 v), XI per channel; fixed per thread
+        constexpr int NXJ = (CIB * XI + 255) / 256;       // 6
+        constexpr int NGJ = (COB * 32) / 256;             // 2 COF: (channel, row, quad v = 0 .. QD - 1 at columns c0 + 4 v), R QD = 32 per channel
+        int xgo[NXJ]; int xlo[NXJ]; unsigned xr = 0, xfl = 0, xok = 0;      // xr / gr: two bits per item = its row of the stage
+        const int n_xi = cit * XI;
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
             const int idx = t + 256 * j, q = min(idx, n_xi - 1);
-            const int c = q / 36, rem = q - c * 36, r = rem / 18, v = rem - r * 18;
+            const int c = q / XI, rem = q - c * XI, r = rem / QX, v = rem - r * QX;
             int gx = c0 - 4 + 4 * v; unsigned fl = 0;
             if (gx < 0) { fl = 1; gx = 0; } else if (gx >= W) { fl = 2; gx = W - 4; }
             xgo[j] = (ci0 + c) * HW + gx;
             xlo[j] = c * XCH + r * (3 * C::XROW) + 8 + 8 * v;
-            xr |= (unsigned)r << j; xfl |= fl << (2 * j); if (idx < n_xi) xok |= 1u << j;
+            xr |= (unsigned)r << (2 * j); xfl |= fl << (2 * j); if (idx < n_xi) xok |= 1u << j;
         }
         int ggo[NGJ]; int glo[NGJ]; unsigned gr = 0;
 #pragma unroll
         for (int j = 0; j < NGJ; ++j) {
-            const int idx = t + 256 * j, c = idx >> 5, r = (idx >> 4) & 1, v = idx & 15;
+            const int idx = t + 256 * j, c = idx >> 5, r = (idx & 31) / QD, v = idx % QD;
             ggo[j] = (co0 + min(c, cot - 1)) * HW + c0 + 4 * v;
             glo[j] = c * DCH + 8 * v;
-            gr |= (unsigned)r << j;
+            gr |= (unsigned)r << (2 * j);
         }
         // two register sets: the loads of stage s + 2 are in flight while stage s + 1 is transformed and stored (one stage of prefetch left the
         // loop waiting on HBM latency: 37 KB in flight per CU)
         struct Regs { float4 xv[NXJ], gv[NGJ], yv[NGJ]; };
         Regs R0, R1;
-        auto fetch_x = [&](Regs& R, int i) {               // padded rows i, i + 1 = image rows reflect(i - 1), reflect(i)
-            const int ro0 = reflect_idx(i - 1, H) * W, ro1 = reflect_idx(i, H) * W;
+        auto pick = [&](const int (&ro)[R], unsigned r) { int v = ro[0]; if (R > 1) v = r == 1 ? ro[1] : v; if (R > 2) { v = r == 2 ? ro[2 % R] : v; v = r == 3 ? ro[3 % R] : v; } return v; };
+        auto fetch_x = [&](Regs& Rg, int i) {              // padded rows i .. i + R - 1 = image rows reflect(i - 1 ..)
+            int ro[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) ro[r] = reflect_idx(i - 1 + r, H) * W;
 #pragma unroll
             for (int j = 0; j < NXJ; ++j) {
 #if defined(X6_DBG_NOLOAD) || defined(X6_DBG_NOPROD)
-                R.xv[j] = make_float4(1.f, 2.f, 3.f, 4.f + ro0 + ro1); continue;
+                Rg.xv[j] = make_float4(1.f, 2.f, 3.f, 4.f + ro[0]); continue;
 #endif
-                R.xv[j] = *reinterpret_cast<const float4*>(xin + xgo[j] + (((xr >> j) & 1u) ? ro1 : ro0));
+                Rg.xv[j] = *reinterpret_cast<const float4*>(xin + xgo[j] + pick(ro, (xr >> (2 * j)) & 3u));
             }
         };
-        auto fetch_dy = [&](Regs& R, int r0) {             // dy rows r0, r0 + 1 (rows outside the image: any valid address, zeroed at the store)
-            const int ro0 = min(max(r0, 0), H - 1) * W, ro1 = min(max(r0 + 1, 0), H - 1) * W;
+        auto fetch_dy = [&](Regs& Rg, int r0) {            // dy rows r0 .. r0 + R - 1 (rows outside the image: any valid address, zeroed at the store)
+            int ro[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) ro[r] = min(max(r0 + r, 0), H - 1) * W;
 #pragma unroll
             for (int j = 0; j < NGJ; ++j) {
-                const int off = ggo[j] + (((gr >> j) & 1u) ? ro1 : ro0);
+                const int off = ggo[j] + pick(ro, (gr >> (2 * j)) & 3u);
 #if defined(X6_DBG_NOLOAD) || defined(X6_DBG_NOPROD)
-                R.gv[j] = make_float4(1.f, 2.f, 3.f, 4.f + off); R.yv[j] = R.gv[j]; continue;
+                Rg.gv[j] = make_float4(1.f, 2.f, 3.f, 4.f + off); Rg.yv[j] = Rg.gv[j]; continue;
 #endif
-                R.gv[j] = *reinterpret_cast<const float4*>(gap + off);
-                if (yp) R.yv[j] = *reinterpret_cast<const float4*>(yp + off);
+                Rg.gv[j] = *reinterpret_cast<const float4*>(gap + off);
+                if (yp) Rg.yv[j] = *reinterpret_cast<const float4*>(yp + off);
             }
         };
         // every fetch is issued unconditionally (stages past the strip re-read its last rows and are never stored): the compiler can then
         // count the loads in flight and wait for the older register set only
-        const int ilast = i0 + 2 * (nst - 1);
-        auto fetch = [&](Regs& R, int s) { const int i = min(i0 + 2 * s, ilast); fetch_dy(R, i); fetch_x(R, i); };
+        const int ilast = i0 + R * (nst - 1);
+        auto fetch = [&](Regs& Rg, int s) { const int i = min(i0 + R * s, ilast); fetch_dy(Rg, i); fetch_x(Rg, i); };
         Regs RP;
-        fetch_dy(RP, i0 - 2); fetch(R0, 0); fetch(R1, 1);
+        fetch_dy(RP, i0 - R); fetch(R0, 0); fetch(R1, 1);
         __syncthreads();                                   // (S0) channel tables visible
         float xm[NXJ], xs[NXJ], xb[NXJ];
 #pragma unroll
-        for (int j = 0; j < NXJ; ++j) { const int c = min(t + 256 * j, n_xi - 1) / 36; const ChanFwd f = s_chx[c]; xm[j] = f.mean; xs[j] = f.scale; xb[j] = f.beta; }
+        for (int j = 0; j < NXJ; ++j) { const int c = min(t + 256 * j, n_xi - 1) / XI; const ChanFwd f = s_chx[c]; xm[j] = f.mean; xs[j] = f.scale; xb[j] = f.beta; }
         X6Bwd gk[NGJ];
 #pragma unroll
         for (int j = 0; j < NGJ; ++j) gk[j] = s_chg[(t + 256 * j) >> 5];
         const bool xlrelu = (A.in.act & 1) != 0; const float xslope = A.in.slope;
-        auto store_x = [&](const Regs& R, char* __restrict__ dst) {
+        auto store_x = [&](const Regs& Rg, char* __restrict__ dst) {
 #ifdef X6_DBG_NOPROD
             return;
 #endif
 #pragma unroll
             for (int j = 0; j < NXJ; ++j) {
-                float e[4] = {R.xv[j].x, R.xv[j].y, R.xv[j].z, R.xv[j].w};
+                float e[4] = {Rg.xv[j].x, Rg.xv[j].y, Rg.xv[j].z, Rg.xv[j].w};
 #pragma unroll
                 for (int l = 0; l < 4; ++l) { float v = __builtin_fmaf(e[l] - xm[j], xs[j], xb[j]); if (xlrelu) v = __builtin_fmaxf(v, v * xslope); e[l] = v; }
                 const unsigned fl = (xfl >> (2 * j)) & 3u;
@@ -216,33 +229,34 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
                 }
             }
         };
-        auto store_dy = [&](const Regs& R, int r0) {       // rows r0, r0 + 1 -> ring slots (r + 2) % 6
-            const int s0 = (r0 + 2) % 6, s1 = (r0 + 3) % 6;
-            const bool inv0 = r0 < 0 || r0 >= H, inv1 = r0 + 1 < 0 || r0 + 1 >= H;
+        auto store_dy = [&](const Regs& Rg, int r0) {      // rows r0 .. r0 + R - 1 -> ring slots (row + 2) % NSLOT
+            int so[R]; bool any_inv = false; unsigned invm = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { so[r] = ((r0 + r + 2 + 2 * NSLOT) % NSLOT) * DSLOT; const bool iv = r0 + r < 0 || r0 + r >= H; any_inv |= iv; invm |= (iv ? 1u : 0u) << r; }
 #ifdef X6_DBG_NOPROD
             return;
 #endif
 #pragma unroll
             for (int j = 0; j < NGJ; ++j) {
-                float e[4] = {R.gv[j].x, R.gv[j].y, R.gv[j].z, R.gv[j].w};
+                float e[4] = {Rg.gv[j].x, Rg.gv[j].y, Rg.gv[j].z, Rg.gv[j].w};
                 if (yp) {
-                    const float yy[4] = {R.yv[j].x, R.yv[j].y, R.yv[j].z, R.yv[j].w};
+                    const float yy[4] = {Rg.yv[j].x, Rg.yv[j].y, Rg.yv[j].z, Rg.yv[j].w};
 #pragma unroll
                     for (int l = 0; l < 4; ++l) e[l] = __builtin_fmaf(yy[l] - gk[j].mean, gk[j].qc, __builtin_fmaf(e[l], gk[j].c1, gk[j].k2));
                 } else {
 #pragma unroll
                     for (int l = 0; l < 4; ++l) e[l] *= gk[j].c1;      // no BatchNorm behind the layer: dy = ga (c1 = 1; 0 for channels beyond the tensor)
                 }
-                const bool r1 = ((gr >> j) & 1u) != 0;
-                if (inv0 | inv1) { if (r1 ? inv1 : inv0) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; } }
+                const unsigned rj = (gr >> (2 * j)) & 3u;
+                if (any_inv) { if ((invm >> rj) & 1u) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; } }
                 u32x2 h, m, l; split4(e, h, m, l);
-                char* d = s_dy + glo[j] + (r1 ? s1 : s0) * DSLOT;
+                char* d = s_dy + glo[j] + pick(so, rj);
                 *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + C::DROW) = m; *reinterpret_cast<u32x2*>(d + 2 * C::DROW) = l;
             }
         };
-        auto store = [&](const Regs& R, int s) { store_dy(R, i0 + 2 * s); store_x(R, s_x + (s & 1) * XBUF); };
-        // prologue: dy rows i0 - 2, i0 - 1, then stage 0 (dy rows i0, i0 + 1 and padded x rows i0, i0 + 1)
-        store_dy(RP, i0 - 2); store(R0, 0);
+        auto store = [&](const Regs& Rg, int s) { store_dy(Rg, i0 + R * s); store_x(Rg, s_x + (s & 1) * XBUF); };
+        // prologue: the dy rows above the strip (i0 - 2, i0 - 1 are read), then stage 0 (dy rows and padded x rows i0 .. i0 + R - 1)
+        store_dy(RP, i0 - R); store(R0, 0);
         fetch(R0, 2);
         lds_barrier();                                     // (A) stage 0 published
         for (int st = 0; st < nst; st += 2) {              // in flight at the top: R1 = stage st + 1 (older), R0 = stage st + 2
@@ -319,28 +333,31 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
             auto loadA = [&](u32x4 (&Aop)[3][3], int seg, int bs) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    int slot = bs - ky; slot += slot < 0 ? 6 : 0;
+                    int slot = bs - ky; slot += slot < 0 ? NSLOT : 0;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) Aop[ky][p] = *reinterpret_cast<const u32x4*>(dyb + slot * DSLOT + p * C::DROW + seg * 64);
                 }
             };
-            // NU units (same padded row, segments 0 .. NU - 1) as one pipelined list of NU * G groups
-            auto units = [&](auto nu_c, int off_x, int seg0, int bs) {
+            // NU units (BW = 64: one padded row, segments seg0 .. ; BW = 32: consecutive rows) as one pipelined list of NU * G groups
+            auto units = [&](auto nu_c, int off_x0, int seg0, int bs0) {
                 constexpr int NU = decltype(nu_c)::value;
+                auto u_off = [&](int u) { return BW == 64 ? off_x0 : off_x0 + u * (3 * C::XROW); };
+                auto u_seg = [&](int u) { return BW == 64 ? seg0 + u : seg0; };
+                auto u_bs = [&](int u) { int b = BW == 64 ? bs0 : bs0 + u; b -= b >= NSLOT ? NSLOT : 0; return b; };
 #ifdef X6_DBG_NOMFMA
                 return;
 #endif
                 u32x4 Aop[NU][3][3], B[2][3]; unsigned raw[2][6];
-                loadA(Aop[0], seg0, bs);
-                issue(0, off_x, seg0, raw[0]);
+                loadA(Aop[0], u_seg(0), u_bs(0));
+                issue(0, u_off(0), u_seg(0), raw[0]);
                 prep(0, raw[0], B[0]);
 #pragma unroll
                 for (int q = 0; q < NU * G; ++q) {
                     const int u = q / G, gi = q - u * G;
                     const int qn = q + 1, un = qn / G, gn = qn - un * G;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (qn < NU * G) issue(gn, off_x, seg0 + un, raw[qn & 1]);
-                    if (NU > 1 && gi == G - 1 && u + 1 < NU) loadA(Aop[(u + 1) % NU], seg0 + u + 1, bs);      // the next unit's dy pieces, under this unit's last group
+                    if (qn < NU * G) issue(gn, u_off(un), u_seg(un), raw[qn & 1]);
+                    if (NU > 1 && gi == G - 1 && u + 1 < NU) loadA(Aop[(u + 1) % NU], u_seg(u + 1), u_bs(u + 1));      // the next unit's dy pieces, under this unit's last group
                     __builtin_amdgcn_sched_barrier(0);
                     if (BIAS && gi == 0) {
 #pragma unroll
@@ -355,18 +372,19 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
                 __builtin_amdgcn_sched_barrier(0);
             };
             constexpr std::integral_constant<int, 1> one_unit{}; constexpr std::integral_constant<int, 2> two_units{};
-            int bs = (i0 + 2) % 6;                                          // ring slot of dy row i0
+            int bs = (i0 + 2) % NSLOT;                                      // ring slot of dy row i0
             for (int st = 0; st < nst; ++st) {
                 const int xb_off = (st & 1) * XBUF;
                 if constexpr (COF == 1) {
-                    const int r = sl >> 1, s = sl & 1;
-                    int b = bs + r; b -= b >= 6 ? 6 : 0;
+                    const int r = BW == 64 ? sl >> 1 : sl, s = BW == 64 ? sl & 1 : 0;
+                    int b = bs + r; b -= b >= NSLOT ? NSLOT : 0;
                     units(one_unit, xb_off + r * (3 * C::XROW), s, b);
                 } else {
-                    int b = bs + sl; b -= b >= 6 ? 6 : 0;
-                    units(two_units, xb_off + sl * (3 * C::XROW), 0, b);
+                    const int r = BW == 64 ? sl : 2 * sl;
+                    int b = bs + r; b -= b >= NSLOT ? NSLOT : 0;
+                    units(two_units, xb_off + r * (3 * C::XROW), 0, b);
                 }
-                bs += 2; bs -= bs >= 6 ? 6 : 0;
+                bs += R; bs -= bs >= NSLOT ? NSLOT : 0;
                 lds_barrier();
             }
             // ---- pixel slices -> LDS (over the staging buffers: every wave is past its last read) ----
@@ -423,14 +441,27 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
     }
 }
 
+template <int COF, int BW>
+int launch_x6k(X6Args& A, dim3 grid, hipStream_t st)
+{
+    using C = X6Cfg<BW>;
+    constexpr size_t stage_bytes = 2 * (size_t)C::XBUF + (size_t)16 * COF * C::DCH, epi_bytes = sizeof(float) * (size_t)(4 / COF) * 16 * COF * C::ROWP;
+    constexpr size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    static_assert(lds_bytes <= 150 * 1024, "LDS budget");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bww_x6_kernel<COF, BW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return (int)attr;
+    mfvi_launch((conv_bww_x6_kernel<COF, BW>), grid, dim3(512), lds_bytes, st, A);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // tune: cof | 11 << 8 | (target blocks / 256) << 16.  Returns -2 when the shape is not served, -3 when the tiling is not valid for it.
 int launch_conv_bwd_weight_x6(const TView& in, const GView& gy, const ConvGeom& g, BwwPart part, int* strips_used, int cof, int target,
                               int n_samples, hipStream_t st)
 {
-    using C = X6Cfg;
-    if (g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 1) || g.H < 4 || g.Cin < 16) return -2;
+    if (g.ks != 3 || g.stride != 1 || (g.W & 31) || (g.H & 1) || g.H < 4 || g.Cin < 16) return -2;
+    const int bw = (g.W & 63) ? 32 : 64, R = 128 / bw;
     const int rem = g.Cin & 15;
     if (rem != 0 && rem != 4) return -2;
     if ((in.sstride & 3) || ((uintptr_t)in.data & 15) || (gy.gstride & 3) || ((uintptr_t)gy.ga & 15) || (gy.y && ((gy.ystride & 3) || ((uintptr_t)gy.y & 15)))) return -2;
@@ -441,7 +472,7 @@ int launch_conv_bwd_weight_x6(const TView& in, const GView& gy, const ConvGeom& 
     const int cob = 16 * cof;
     const int ci_groups = (g.Cin % 32 == 4 || g.Cin % 32 == 0) ? g.Cin / 32 : g.Cin / 32 + 1;       // 36 -> 1, 68 -> 2, 132 -> 4, 48 -> 2 (32 + 16), 52 -> 2 (32 + 20)
     const int co_tiles = (g.Cout + cob - 1) / cob;
-    const int bands = g.W / 64, pr2 = (g.H + 2) / 2;                       // stages over the whole map
+    const int bands = g.W / bw, pr2 = (g.H + 2 + R - 1) / R;               // stages over the whole map
     const long long pairs = (long long)co_tiles * ci_groups * n_samples * bands;
     int strips = (int)((target + pairs - 1) / pairs);
     strips = strips < 1 ? 1 : (strips > pr2 ? pr2 : strips);
@@ -451,19 +482,12 @@ int launch_conv_bwd_weight_x6(const TView& in, const GView& gy, const ConvGeom& 
     strips = (pr2 + spb - 1) / spb;
     X6Args A{};
     A.in = in; A.gy = gy; A.g = g; A.part = part.base; A.part_stride = part.stride;
-    A.bands = bands; A.rps = 2 * spb; A.ci_groups = ci_groups;
+    A.bands = bands; A.rps = R * spb; A.ci_groups = ci_groups;
     A.nx = strips * bands; A.ny = co_tiles * ci_groups; A.nz = n_samples;
-    const size_t stage_bytes = 2 * (size_t)C::XBUF + (size_t)cob * C::DCH;
-    const size_t epi_bytes = sizeof(float) * (size_t)(4 / cof) * cob * C::ROWP;
-    const size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-    hipError_t attr;
-    if (cof == 1) { static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bww_x6_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = a1; }
-    else { static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bww_x6_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = a2; }
-    if (attr != hipSuccess) return (int)attr;
-    if (lds_bytes > 150 * 1024) return -3;
     const dim3 grid(A.nx * A.ny * A.nz);
-    if (cof == 1) mfvi_launch(conv_bww_x6_kernel<1>, grid, dim3(512), lds_bytes, st, A);
-    else mfvi_launch(conv_bww_x6_kernel<2>, grid, dim3(512), lds_bytes, st, A);
-    if (strips_used) *strips_used = strips * bands;
-    return (int)hipGetLastError();
+    int rc;
+    if (bw == 64) rc = cof == 1 ? launch_x6k<1, 64>(A, grid, st) : launch_x6k<2, 64>(A, grid, st);
+    else rc = cof == 1 ? launch_x6k<1, 32>(A, grid, st) : launch_x6k<2, 32>(A, grid, st);
+    if (rc == 0 && strips_used) *strips_used = strips * bands;
+    return rc;
 }

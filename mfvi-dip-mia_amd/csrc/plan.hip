@@ -1027,7 +1027,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
             else {
                 for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16);
                 for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(2 | 10 << 8 | tb << 16);      // fragment-split variant (3x3 stride 1, full-width tiles)
-                if (o.g.ks == 3 && o.g.stride == 1 && (o.g.W & 63) == 0)                         // bf16x6 kernel (conv_bww_x6.hip)
+                if (o.g.ks == 3 && o.g.stride == 1 && (o.g.W & 31) == 0)                         // bf16x6 kernel (conv_bww_x6.hip)
                     for (int cof = 1; cof <= 2; ++cof) for (int tb = 1; tb <= 4; tb *= 2) cands.push_back(cof | 11 << 8 | tb << 16);
             }
             int best = 0; float best_ms = 1e30f;

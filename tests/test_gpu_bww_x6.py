@@ -17,7 +17,9 @@ def enc(a, b, c):
 
 
 @pytest.mark.parametrize("shape", [(36, 16, 16, 64), (68, 32, 8, 128), (16, 16, 32, 64), (32, 32, 8, 64), (20, 16, 4, 64), (132, 64, 8, 64),
-                                   (48, 16, 6, 128), (52, 48, 12, 64), (100, 24, 8, 64)])
+                                   (48, 16, 6, 128), (52, 48, 12, 64), (100, 24, 8, 64),
+                                   # maps 32 (96) wide: bands of 32 pixels, four padded rows per stage (H + 2 not a multiple of 4: zero rows below the map)
+                                   (36, 16, 8, 32), (68, 32, 32, 32), (64, 64, 12, 32), (132, 48, 6, 96), (20, 16, 4, 32)])
 def test_x6_backward_weight_against_fp32_mfma(M, shape):
     """conv -> BN+act -> 3x3 (under test) -> BN+act -> conv.  Every channel grouping (one / two input fragments per block, with and without
     the 4-channel remainder fragment, several groups, output channels not a multiple of the block's), one and two output fragments per
@@ -42,7 +44,7 @@ def test_x6_backward_weight_against_fp32_mfma(M, shape):
     assert tried == 4
 
 
-@pytest.mark.parametrize("case", [(36, 16, 8, 64), (16, 32, 12, 128)])
+@pytest.mark.parametrize("case", [(36, 16, 8, 64), (16, 32, 12, 128), (36, 32, 10, 32)])
 def test_x6_backward_weight_against_float64(M, case):
     """Single layer from the plan's input (no BatchNorm on either side): d mu / d rho against the gradient restated in float64."""
     cin, cout, H, W = case
