@@ -27,6 +27,8 @@
  *      MFVI_TUNE=mf,th,T       force one tiling of the round-2 MFMA forward / backward-data kernels where the plan holds none
  *      MFVI_TUNE_W=nb,w,tgt    the same for the backward-weight kernels
  *      MFVI_RP=0               keep the 3x3 stride-1 layers on the round-2 kernels (row-phase kernels of conv_rp.hip off)
+ *      MFVI_X6=0               heuristic tilings (no autotune): backward-weight never on the bf16x6 kernel (conv_bww_x6.hip); the autotuner's
+ *                              candidates and explicit tilings (w = 11; forward: tune bit 25, conv_x6.hip) are not affected
  *      MFVI_TUNE_RP=mf,r,T[,rem[,ks]]  force one row-phase tiling where the plan holds none
  *      MFVI_PHASE=0            stride-2 backward-data: zero-stuffed formulation instead of the phase decomposition
  *      MFVI_FOLD_FUSION=0      1x1 backward-data writes the padded gradient + a finalize_dx launch (fold not fused)

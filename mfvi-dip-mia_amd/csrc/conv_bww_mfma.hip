@@ -674,7 +674,14 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
     int cfg = g.tune[2] ? g.tune[2] : env_tune_w();
     const bool forced = cfg != 0;
     if (!cfg) {
-        // heuristic: stage dy once for up to 48 input channels when the layer has them; 8 waves when the tile is big
+        // heuristic: the bf16x6 kernel where it serves the shape and measured ahead of the fp32 ones (3x3 stride 1, >= 32 input channels, maps a
+        // multiple of 32 wide: profiles/r03_x6_layers.txt); otherwise stage dy once for up to 48 input channels when the layer has them, 8 waves
+        // when the tile is big
+        static const bool x6_on = [] { const char* e = getenv("MFVI_X6"); return !(e && e[0] == '0'); }();
+        if (x6_on && g.ks == 3 && g.stride == 1 && !(g.W & 31) && !(g.H & 1) && g.H >= 4 && g.Cin >= 32 && ((g.Cin & 15) == 0 || (g.Cin & 15) == 4)) {
+            const int rc = launch_conv_bwd_weight_x6(in, gy, g, part, strips_used, g.Cout >= 32 ? 2 : 1, 256, n_samples, st);
+            if (rc != -2 && rc != -3) return rc;
+        }
         const int nb = g.ks == 5 ? 1 : (g.Cin > 32 ? 3 : (g.Cin > 16 ? 2 : 1));
         cfg = nb | ((nb >= 2 || g.ks == 5 ? 9 : 4) << 8) | ((nb >= 2 ? 1 : 6) << 16);
     }

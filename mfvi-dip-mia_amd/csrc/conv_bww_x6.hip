@@ -141,7 +141,10 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
 
     if (producer) {
         // ======================= staging waves =======================
-        __builtin_amdgcn_s_setprio(2);
+#ifndef X6_PRODPRIO
+#define X6_PRODPRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(X6_PRODPRIO);
         // x items: (channel c, row r of the stage, quad v = 0 .. QX - 1 at image columns c0 - 4 + 4 v), XI per channel; fixed per thread
         constexpr int NXJ = (CIB * XI + 255) / 256;       // 6
         constexpr int NGJ = (COB * 32) / 256;             // 2 COF: (channel, row, quad v = 0 .. QD - 1 at columns c0 + 4 v), R QD = 32 per channel
@@ -273,6 +276,9 @@ __global__ __launch_bounds__(512, 2) void conv_bww_x6_kernel(X6Args A)
         const int cf = COF == 1 ? 0 : (wv & 1), sl = COF == 1 ? wv : (wv >> 1);      // output fragment, pixel slice
         const char* const dyb = s_dy + (cf * 16 + l15) * DCH + l4 * 16;
         const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#ifdef X6_CONSPRIO
+        __builtin_amdgcn_s_setprio(X6_CONSPRIO);
+#endif
         __syncthreads();                                   // (S0)
         lds_barrier();                                     // (A)
         auto consume = [&](auto nf_c, auto x4_c, auto bias_c) {

@@ -177,11 +177,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
         if (c_halo) { c_row = lane >> 1; c_col = (lane & 1) ? 65 : 0; c_oct = pw; }
         else { const int id = min(pw * 33 + lane - 4, 131); c_row = id / 66; c_col = id - c_row * 66; c_oct = 4; }
         int gxc = c0 - 1 + c_col; gxc = reflect_idx(gxc, W);          // image column of the third-round pixel
-        float va[2][8], vb[2][8], vc[2][8];
+        constexpr int NSET = 4;                             // register sets: the loads of stages s + 2 .. s + 4 are in flight while stage s + 1 is stored (two sets = 49 KB in flight per CU left ~30 % of the load latency exposed)
+        float va[NSET][8], vb[NSET][8], vc[NSET][8];
         const int ilast = n_stage - 1;
         auto fetch = [&](int set, int q) {                           // stage q = group cg, input rows 2 s, 2 s + 1 of the strip window
-#ifdef X6F_DBG_NOPROD
-            for (int j = 0; j < 8; ++j) { va[set][j] = 1.f; vb[set][j] = 2.f; vc[set][j] = 3.f; } return;
+#if defined(X6F_DBG_NOPROD) || defined(X6F_DBG_NOLOAD)
+            for (int j = 0; j < 8; ++j) { va[set][j] = 1.f + q; vb[set][j] = 2.f; vc[set][j] = 3.f; } return;
 #endif
             q = min(q, ilast);
             const int ts = q / n_stage1, r0 = (strip0 + ts) * SR; q -= ts * n_stage1;
@@ -204,7 +205,11 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
                 const ChanFwd f = s_ch[cbase + j];
                 float x = __builtin_fmaf(v[j] - f.mean, f.scale, f.beta); if (xlrelu) x = __builtin_fmaxf(x, x * xslope); e[j] = x;
             }
+#ifdef X6F_DBG_NOSPLIT
+            u32x4 h = {__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])}, m = {__float_as_uint(e[4]), __float_as_uint(e[5]), __float_as_uint(e[6]), __float_as_uint(e[7])}, l = h;
+#else
             u32x4 h, m, l; split8(e, h, m, l);
+#endif
             *reinterpret_cast<u32x4*>(dst) = h; *reinterpret_cast<u32x4*>(dst + NOCT * PLANE) = m; *reinterpret_cast<u32x4*>(dst + 2 * NOCT * PLANE) = l;
         };
         auto store = [&](int set, int q) {
@@ -242,25 +247,27 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
         };
         constexpr int SPP = (SR + 2) / 2;                   // stages per pass
         wfetch(0);
-        fetch(0, 0); fetch(1, 1);
+        fetch(0, 0); fetch(1, 1); fetch(2, 2); fetch(3, 3);
         __syncthreads();                                   // (S0) channel tables visible
         wstore();
         store(0, 0);
-        fetch(0, 2);
+        fetch(0, 4);
         lds_barrier();                                     // (A) stage 0 and the first pass's weights published
         auto wstep = [&](int q) {                          // behind the x store of stage q + 1
             const int s1 = (q + 1) % SPP, pp = (q + 1) / SPP;
             if (s1 == 1 && pp + 1 < n_pass) wfetch(pp + 1);
             if (s1 == 2 && pp + 1 < n_pass) wstore();
         };
-        for (int q = 0; q < n_stage; q += 2) {             // in flight at the top: set 1 = stage q + 1 (older), set 0 = stage q + 2
-            if (q + 1 < n_stage) { store(1, q + 1); wstep(q); }
-            fetch(1, q + 3);
-            lds_barrier();
-            if (q + 1 >= n_stage) break;
-            if (q + 2 < n_stage) { store(0, q + 2); wstep(q + 1); }
-            fetch(0, q + 4);
-            lds_barrier();
+        // in flight at the top of a round: sets 1, 2, 3, 0 = stages q + 1 .. q + 4 (oldest first); every fetch is unconditional
+        // (stages past the block's last re-read it and are never stored), so the compiler counts the loads and waits for the oldest set only
+        for (int q = 0; q < n_stage; q += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q + u >= n_stage) break;
+                if (q + u + 1 < n_stage) { store((u + 1) & 3, q + u + 1); wstep(q + u); }
+                fetch((u + 1) & 3, q + u + 5);
+                lds_barrier();
+            }
         }
         if (A.out.stats != nullptr) __syncthreads();       // (Z)
     } else {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# times the bf16x6 backward-weight kernel for the timing-only variants built by build_variant.sh (results of those builds are wrong by design)
+# times the bf16x6 backward-weight kernel for library variants built by build_variant.sh (X6_VARIANTS = suffixes of mfvi-dip-mia_amd/libvar_*.so)
 for v in "" ${X6_VARIANTS:-NOPROD NOMFMA}; do
   lib=mfvi-dip-mia_amd/libmfvi_hip.so; [ -n "$v" ] && lib=mfvi-dip-mia_amd/libvar_$v.so
   echo "== variant ${v:-full} =="
