@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MFVI_ABI_VERSION 3
+#define MFVI_ABI_VERSION 4
 
 typedef struct mfvi_plan mfvi_plan;
 
@@ -169,6 +169,12 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
  * fragments dealt to the consumer waves); 0 = built-in heuristic. */
 int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which);
 int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
+/* Kernel family that served conv op `op` in its last forward (which 0) / backward-data (1) / backward-weight (2) launch: 0 = generic fp32
+ * VALU kernels (also: a tiling the shape does not admit falls back to them), 1 = fp32 MFMA kernels, 2 = row-phase fp32 MFMA kernels
+ * (3x3 stride 1, maps a multiple of 64 wide), 3 = bf16x6 kernels (fp32 operands as three bf16 pieces on the bf16 matrix instruction:
+ * forward tune bit 25 = mf | rows << 8 | strips per block << 16; backward-weight w = 11, input tiles field = output fragments per block).
+ * -1: bad arguments.  Tests use it to prove that the kernel under test is the one that ran. */
+int mfvi_plan_last_kernel(const mfvi_plan* plan, int op, int which);
 
 /* ---- losses -------------------------------------------------------------------------------------------- */
 /* gaussian_nll (utils/bayesian_utils.py:29-32) for n samples of out[n][2][H][W] against target[H/f][W/f];

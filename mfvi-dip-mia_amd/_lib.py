@@ -45,6 +45,7 @@ SIGNATURES = {
     "mfvi_plan_profile_read": (_I, [_P, _I, _P, _P, _P, _P]),
     "mfvi_plan_autotune": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mfvi_plan_get_tune": (_I, [_P, _I, _I]),
+    "mfvi_plan_last_kernel": (_I, [_P, _I, _I]),
     "mfvi_plan_set_tune": (_I, [_P, _I, _I, _I]),
     "mfvi_gaussian_nll": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "mfvi_gaussian_nll_inpainting": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),

@@ -9,6 +9,9 @@
 // packet of its own (scripts/micro/fork_gap.hip: hipEventRecord + hipStreamWaitEvent add 5.1 us to the recording stream per fork, the
 // event on the kernel's packet 1.8 us).  Not armed (the normal case, and every launch outside mfvi_backward): a plain launch.
 extern thread_local hipEvent_t mfvi_tl_stop_event;
+// kernel family of the conv launch in progress, for mfvi_plan_last_kernel: the plan sets 1 (fp32 MFMA kernels) in front of an MFMA-path
+// launcher, the row-phase launchers (conv_rp.hip) overwrite it with 2, the bf16x6 launchers (conv_x6.hip, conv_bww_x6.hip) with 3
+extern thread_local int mfvi_tl_family;
 template <typename F, typename... Args>
 inline void mfvi_launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args)
 {

@@ -456,6 +456,7 @@ int launch_x6k(X6Args& A, dim3 grid, hipStream_t st)
     static_assert(lds_bytes <= 150 * 1024, "LDS budget");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bww_x6_kernel<COF, BW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return (int)attr;
+    mfvi_tl_family = 3;
     mfvi_launch((conv_bww_x6_kernel<COF, BW>), grid, dim3(512), lds_bytes, st, A);
     return (int)hipGetLastError();
 }

@@ -606,6 +606,7 @@ int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
     constexpr int WCH = KS * (MF * 4 * 16 * 12 + (REM ? 4 * 4 * 12 : 0));
     const size_t dyn = sizeof(float) * 2 * WCH + sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(RpBwd) * (size_t)((g.Cout + 3) & ~3);
     constexpr int MINW = 4;
+    mfvi_tl_family = 2;
     mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, KS, MINW>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
     return (int)hipGetLastError();
 }

@@ -388,6 +388,7 @@ int launch_one(X6FArgs& A, hipStream_t st)
     constexpr size_t lds_bytes = (size_t)C::NSLOT * C::SLOT + (size_t)27 * 16 * MF * 64;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6_kernel<MF, SR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return (int)attr;
+    mfvi_tl_family = 3;
     mfvi_launch((conv_fwd_x6_kernel<MF, SR>), dim3(A.nx * A.ny * A.nz), dim3(512), lds_bytes, st, A);
     return (int)hipGetLastError();
 }

@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...)
 }
 
 thread_local hipEvent_t mfvi_tl_stop_event = nullptr;      // see mfvi_launch (common.h)
+thread_local int mfvi_tl_family = 0;
 
 namespace {
 
@@ -41,6 +42,7 @@ struct OpInfo {
     long long part_off = -1, part_stride = 0;  // floats: partial-dW slabs of the MFMA backward-weight kernel [strip][sample][stride]
     int max_strips = 0;
     long long x6w_off = -1;                    // floats: split weight pieces of the bf16x6 forward (conv_x6.hip), -1: shape not served
+    mutable int family[3] = {0, 0, 0};         // kernel family of the last forward / backward-data / backward-weight launch (mfvi_plan_last_kernel)
 };
 
 inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
@@ -614,8 +616,10 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
             }
         } else if (o.d.type == MFVI_OP_CONV) {
             mfvi_tl_x6w = (presample && o.x6w_off >= 0) ? c.farena() + o.x6w_off : nullptr; mfvi_tl_x6w_ready = x6_ready;
+            mfvi_tl_family = 1;
             rc = use_mfma() ? launch_conv_fwd_mfma(c.view(o.d.in0), o.g, wsrc, wstride, od, n_samples, st) : -2;
             mfvi_tl_x6w = nullptr; mfvi_tl_x6w_ready = false;
+            o.family[0] = (rc == -2 || rc == -3) ? 0 : mfvi_tl_family;
             if ((rc == -2 || rc == -3) && !mu) { set_error("forward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table (use H, W multiples of 4)", (int)i); if (plan->side) (void)hipStreamSynchronize(plan->side); return -1; }
             if (rc == -2 || rc == -3) rc = launch_conv_fwd(c.view(o.d.in0), o.g, mu, rho, key, sample_weights, od, n_samples, st);
         } else {
@@ -787,7 +791,9 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
               int strips = 0;
               const bool arm_join = fork_on_packet && plan->prof_mode != 1 && sw != st && i == last_fork_op;
               if (arm_join) mfvi_tl_stop_event = plan->join_event;
+              mfvi_tl_family = 1;
               rc = use_mfma() ? launch_conv_bwd_weight_mfma(xin, gy, o.g, BwwPart{c.farena() + o.part_off, o.part_stride, o.max_strips}, &strips, n_samples, sw) : -2;
+              o.family[2] = (rc == -2 || rc == -3) ? 0 : mfvi_tl_family;
               if (arm_join) { join_on_packet = mfvi_tl_stop_event == nullptr; mfvi_tl_stop_event = nullptr; }
               if (rc == 0) {
                   GradFinEntry e{};
@@ -812,15 +818,19 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                     ff.bsums = x.d.has_bn ? c.bsums() + x.stats_off : nullptr;
                     ProfScope ps(plan, i, PASS_BWD_DATA, st);
                     { const int ra = arm(i); if (ra) return ra; }
+                    mfvi_tl_family = 1;
                     const int r2 = launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, nullptr, 0, n_samples, st, &ff);
                     settle();
+                    if (r2 == 0) o.family[1] = mfvi_tl_family;
                     if (r2 == 0) folded = true; else { armed_idx = -1; if (r2 != -2 && r2 != -3) rc = r2; }
                 }
                 const bool fold_here = x.consumers.front() == i;
                 if (!rc && !folded) {
                   ProfScope ps(plan, i, PASS_BWD_DATA, st);
                   if (!fold_here) { const int ra = arm(i); if (ra) return ra; }      // no fold behind it: this is the op's last launch on `st`
+                  mfvi_tl_family = 1;
                   rc = use_mfma() ? launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, c.farena() + o.scratch_off, per, n_samples, st) : -2;
+                  o.family[1] = (rc == -2 || rc == -3) ? 0 : mfvi_tl_family;
                   if (!fold_here) { settle(); if (rc) armed_idx = -1; }
                   if ((rc == -2 || rc == -3) && !mu) { set_error("backward: op %d needs the generic fp32 kernels, which bf16 parameters reach only for layers outside the sampling table", i); rc = -1; }
                   if (rc == -2 || rc == -3) rc = launch_conv_bwd_data(gy, o.g, mu, rho, key, sample_weights, c.farena() + o.scratch_off, per, n_samples, st); }
@@ -930,6 +940,12 @@ int mfvi_plan_profile_read(mfvi_plan* plan, int capacity, int* n_records, int* o
     plan->recs.clear();
     *n_records = n;      /* may exceed capacity: only the first `capacity` were written */
     return 0;
+}
+
+int mfvi_plan_last_kernel(const mfvi_plan* plan, int op, int which)
+{
+    if (!plan || op < 0 || op >= (int)plan->ops.size() || which < 0 || which > 2 || plan->ops[op].d.type != MFVI_OP_CONV) return -1;
+    return plan->ops[op].family[which];
 }
 
 int mfvi_plan_get_tune(const mfvi_plan* plan, int op, int which)

@@ -37,6 +37,7 @@ def test_x6_backward_weight_against_fp32_mfma(M, shape):
         for tgt in (1, 4):
             M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 2, enc(cof, 11, tgt)))
             got = _run_plan(plan, P, seed, n, z, dout)
+            assert lib.mfvi_plan_last_kernel(plan.handle, 1, 2) == 3, "the bf16x6 kernel did not run"
             tried += 1
             assert np.array_equal(got[0], ref[0])
             for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
@@ -76,5 +77,6 @@ def test_x6_backward_weight_against_float64(M, case):
         plan.forward(d_mu, d_rho, bn, d_x, seed, step, k0, n)
         dmu = torch.zeros_like(d_mu); drho = torch.zeros_like(d_rho); dbn = torch.zeros_like(bn)
         plan.backward(d_mu, d_rho, bn, d_x, seed, step, k0, n, d_dy, dmu, drho, dbn)
+        assert lib.mfvi_plan_last_kernel(plan.handle, 0, 2) == 3, "the bf16x6 kernel did not run"
         assert relerr(host(dmu), want_mu) < 5e-6, cof
         assert relerr(host(drho), want_rho) < 5e-6, cof

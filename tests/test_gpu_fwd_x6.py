@@ -35,6 +35,7 @@ def test_x6_forward_against_oracle(M, case):
     for mf, T in ((1, 1), (2, 1), (1, 2), (2, 3)):
         M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, mf | 8 << 8 | T << 16 | X6))
         yh = host(plan.forward(d_mu, d_rho, bn, d_x, seed, step, k0, n))
+        assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) == 3, "the bf16x6 kernel did not run"
         for i in range(n):
             ew = O.eps(seed, step, k0 + i, 0, 0, nw); eb = O.eps(seed, step, k0 + i, 0, 1, cout)
             w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, 3, 3); b = O.reparam(mu[nw:], rho[nw:], eb)
@@ -56,6 +57,7 @@ def test_x6_forward_against_fp32_mfma(M, shape):
     for mf, T in ((1, 1), (2, 1), (1, 2), (2, 4)):
         M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, mf | 8 << 8 | T << 16 | X6))
         got = _run_plan(plan, P, seed, n, z, dout)
+        assert lib.mfvi_plan_last_kernel(plan.handle, 1, 0) == 3, "the bf16x6 kernel did not run"
         assert relerr(got[0], ref[0]) < 2e-6, ("out", mf)
         for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
             assert relerr(a, b) < 2e-5, (name, mf)
