@@ -189,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
             const int cg = q / ((SR + 2) / 2), s = q - cg * ((SR + 2) / 2);
             const int ra = reflect_idx(r0 - 1 + 2 * s, H) * W, rb = reflect_idx(r0 + 2 * s, H) * W;
             const int cgm = min(cg, ncg - 1);                        // (remainder pass: the main rounds re-read the last group, unused)
+            // (float2 loads of a pixel pair per lane — half as many load instructions against the 6-bit vmcnt — were measured: 2-6 % slower)
             const float* __restrict__ p = xin + (long long)(cgm * 32 + pw * 8) * HW + c0 + lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { va[set][j] = p[(long long)j * HW + ra]; vb[set][j] = p[(long long)j * HW + rb]; }
@@ -198,13 +199,23 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
             for (int j = 0; j < 8; ++j) vc[set][j] = pc[(long long)min(cb + j, Cin - 1) * HW];
         };
         const bool xlrelu = (A.in.act & 1) != 0; const float xslope = A.in.slope;
-        auto put = [&](const float (&v)[8], int cbase, char* dst) {
-            float e[8];
+        // channel constants of the running pass in registers (read from the LDS table once per pass, not once per staged pixel): the
+        // transform is v = x * scale + shift, shift = beta - mean * scale formed once per channel
+        float kas[8], kah[8], kcs[8], kch[8];
+        int k_cg = -1;
+        auto load_consts = [&](int cg) {
+            const int ca = min(cg, ncg - 1) * 32 + pw * 8, cc = (cg < ncg && c_halo) ? ca : (rem ? Cin - 4 : Cin);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const ChanFwd f = s_ch[cbase + j];
-                float x = __builtin_fmaf(v[j] - f.mean, f.scale, f.beta); if (xlrelu) x = __builtin_fmaxf(x, x * xslope); e[j] = x;
+                const ChanFwd f = s_ch[ca + j]; kas[j] = f.scale; kah[j] = __builtin_fmaf(-f.mean, f.scale, f.beta);
+                const ChanFwd g2 = s_ch[cc + j]; kcs[j] = g2.scale; kch[j] = __builtin_fmaf(-g2.mean, g2.scale, g2.beta);
             }
+            k_cg = cg;
+        };
+        auto put = [&](const float (&v)[8], const float (&ks)[8], const float (&kh)[8], char* dst) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float x = __builtin_fmaf(v[j], ks[j], kh[j]); if (xlrelu) x = __builtin_fmaxf(x, x * xslope); e[j] = x; }
 #ifdef X6F_DBG_NOSPLIT
             u32x4 h = {__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])}, m = {__float_as_uint(e[4]), __float_as_uint(e[5]), __float_as_uint(e[6]), __float_as_uint(e[7])}, l = h;
 #else
@@ -217,13 +228,14 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
             return;
 #endif
             const int cg = (q % n_stage1) / ((SR + 2) / 2);
+            if (cg != k_cg) load_consts(cg);
             const int sa = (2 * q) & 3, sb = (2 * q + 1) & 3;                  // ring slots of the stage's two rows
             if (cg < ncg) {
                 char* base = lds + pw * PLANE + (1 + lane) * 16;
-                put(va[set], cg * 32 + pw * 8, base + sa * SLOT);
-                put(vb[set], cg * 32 + pw * 8, base + sb * SLOT);
+                put(va[set], kas, kah, base + sa * SLOT);
+                put(vb[set], kas, kah, base + sb * SLOT);
             }
-            if (cg < ncg ? c_halo : c_rem) put(vc[set], c_halo ? cg * 32 + pw * 8 : Cin - 4, lds + (c_row ? sb : sa) * SLOT + c_oct * PLANE + c_col * 16);
+            if (cg < ncg ? c_halo : c_rem) put(vc[set], kcs, kch, lds + (c_row ? sb : sa) * SLOT + c_oct * PLANE + c_col * 16);
         };
         (void)c_on;
         // weight pieces of pass pp (strip pp / passes, group pp % passes): 27 (remainder: 9) chunks of COB x 64 bytes -> s_w, requested in

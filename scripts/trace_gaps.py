@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-iteration timeline from a rocprofv3 --kernel-trace CSV: span, sum of kernel durations, idle gaps (by the kernel that
-precedes them).  Iterations are delimited by adam_kernel launches.  Usage: trace_gaps.py <*_kernel_trace.csv>"""
+precedes them).  Iterations are delimited by the adam_kernel / elbo_update_kernel launches.  Usage: trace_gaps.py <*_kernel_trace.csv>"""
 import csv
 import sys
 from collections import defaultdict
@@ -10,7 +10,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2] or "elbo_update" in r[2]]
 print("kernels", len(rows), "adam launches", len(adam))
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
 for a, b in list(zip(adam[:-1], adam[1:]))[-3:]:
