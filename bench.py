@@ -433,6 +433,14 @@ def main():
             "final_loss": loss, "final_nll": nll, "final_kl": kl,
             "roofline": roof,
         }
+        # convolutions that ran on the bf16 matrix instruction with three-way split fp32 operands (same fp32 results: DESIGN.md section 1)
+        try:
+            from mfvi_dip_mia_amd import _lib as L_
+            fam = lambda i, w: L_.lib().mfvi_plan_last_kernel(eng.plan.handle, i, w)
+            res["bf16x6_kernels"] = ["%s:%s" % (n_, conv_cost(eng.prog, i, 1)["desc"]) for i, o_ in enumerate(eng.prog.ops) if o_["type"] == 1
+                                     for w, n_ in ((0, "fwd"), (1, "bwd_data"), (2, "bwd_weight")) if fam(i, w) == 3]
+        except Exception:
+            res["bf16x6_kernels"] = None
         if strong_extra:
             res["strong_scaling"] = strong_extra
         if world > 1:

@@ -536,7 +536,10 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
             hipError_t e = hipSuccess;
             if (!plan->x6_dev) e = hipMalloc((void**)&plan->x6_dev, sizeof(X6SplitEntry) * plan->ops.size());
             const bool same = tab.size() == plan->x6_uploaded.size() && memcmp(tab.data(), plan->x6_uploaded.data(), sizeof(X6SplitEntry) * tab.size()) == 0;
-            if (e == hipSuccess && !same) { e = hipMemcpyAsync(plan->x6_dev, tab.data(), sizeof(X6SplitEntry) * tab.size(), hipMemcpyHostToDevice, st); plan->x6_uploaded = tab; }
+            if (e == hipSuccess && !same) {      // (copied from the plan's own vector: it outlives the asynchronous copy)
+                plan->x6_uploaded = tab;
+                e = hipMemcpyAsync(plan->x6_dev, plan->x6_uploaded.data(), sizeof(X6SplitEntry) * tab.size(), hipMemcpyHostToDevice, st);
+            }
             if (e != hipSuccess) { set_error("forward: weight-piece table setup failed: %s", hipGetErrorString(e)); return (int)e; }
             const int rc = launch_x6_split_all(plan->x6_dev, (int)tab.size(), nb, c.wsamp(), sample_weights ? plan->n_vi : 0, sample_weights ? n_samples : 1, c.farena(), st);
             if (rc) { set_error("forward: weight-piece launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }

@@ -5,6 +5,7 @@
 #   3. HBM traffic: two PMC passes (FETCH_SIZE, WRITE_SIZE; counters + kernel trace only, side stream off) joined with launch durations
 #   4. HBM traffic and SQ counters of the three dominant 3x3 layers, one at a time (every kernel alone on the stream)
 #   5. bench line + kernel stats of the other BASELINE configs
+#   6. the bf16x6 kernels over their tilings (x6_layers.py) and the SQ counters of a layer they serve in two passes
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/prof_r03; rm -rf $OUT; mkdir -p $OUT
@@ -28,6 +29,10 @@ rm -f $OUT/pmc_sq_up9.txt; scripts/dev/pmc_sq.sh $OUT/pmc_sq_up9.txt 36 16 3 1 2
 echo "done layer profiles"
 python3 scripts/dev/rp_layers.py > $OUT/rp_layers.txt 2>/dev/null
 echo "done rp_layers"
+# bf16x6 kernels (conv_bww_x6.hip, conv_x6.hip): every tiling on the three dominant layers + the 32-wide layer; SQ counters of 68->32 (forward and backward-weight both bf16x6 there)
+python3 scripts/dev/x6_layers.py 36 16 256 68 32 128 132 64 64 132 128 32 > $OUT/x6_layers.txt 2>/dev/null
+rm -f $OUT/pmc_sq_up7.txt; scripts/dev/pmc_sq.sh $OUT/pmc_sq_up7.txt 68 32 3 1 128 128
+echo "done x6 layers"
 export MFVI_TUNE_CACHE=$R/$OUT/tunes_cfg2_k1.json
 python3 bench.py --k 1 > $OUT/bench_cfg2_k1.json 2> /dev/null
 (cd /tmp && rm -rf /tmp/p_k1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_k1 -- python3 $R/bench.py --k 1 --steps 50 --warmup 3 --no-cpu-baseline > /dev/null 2>&1)
