@@ -1181,14 +1181,17 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
     // aligned float4 staging: image rows, sample strides and the base pointer must be multiples of 4 floats
     if ((g.W & 3) || g.W < 4 || (in.sstride & 3) || ((uintptr_t)in.data & 15)) return -2;
     {   // row-phase kernels (conv_rp.hip): an explicit tiling of the plan / autotuner, or the default for the shapes they serve
-        const int tn = g.tune[0] ? g.tune[0] : (env_tune() ? 0 : rp_default_tune(g, 0, n_samples));
+        int tn = g.tune[0] ? g.tune[0] : (env_tune() ? 0 : rp_default_tune(g, 0, n_samples));
         if (tn & MFVI_TUNE_X6) {      // bf16x6 forward (conv_x6.hip): only as an explicit tiling of the plan / autotuner
             const int rc = launch_conv_fwd_x6(in, g, w, wstride, out, tn & (MFVI_TUNE_X6 - 1), n_samples, st);
-            return rc == -2 ? -3 : rc;
+            if (rc != -2) return rc;
+            // no scratch for the weight pieces in this call (w = mu of the eval branch, sample_weights = 0: the plan hands the scratch over
+            // only behind a weight draw): the layer's fp32 default, not the generic kernels
+            tn = env_tune() ? 0 : rp_default_tune(g, 0, n_samples);
         }
         if (tn & MFVI_TUNE_RP) {
             const int rc = launch_conv_fwd_rp(in, g, w, wstride, out, tn & (MFVI_TUNE_RP - 1), n_samples, st);
-            if (rc != -2 || g.tune[0]) return rc == -2 ? -3 : rc;
+            if (rc != -2 || (g.tune[0] & MFVI_TUNE_RP)) return rc == -2 ? -3 : rc;
         }
     }
     GView none{};

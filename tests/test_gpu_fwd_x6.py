@@ -40,6 +40,10 @@ def test_x6_forward_against_oracle(M, case):
             ew = O.eps(seed, step, k0 + i, 0, 0, nw); eb = O.eps(seed, step, k0 + i, 0, 1, cout)
             w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, 3, 3); b = O.reparam(mu[nw:], rho[nw:], eb)
             assert relerr(yh[i], O.conv_fwd(x, w, b, 1)) < 2e-6, ("fwd", mf, i)
+    # eval branch (w = mu, no weight draw, so no scratch for the pieces): the tiling stays set, the layer runs on its fp32 default
+    y0 = plan.forward(d_mu, d_rho, bn, d_x, seed, step, k0, 1, sample_weights=False)
+    assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) == 2, "expected the row-phase fp32 kernel"
+    assert relerr(host(y0)[0], O.conv_fwd(x, mu[:nw].reshape(cout, cin, 3, 3), mu[nw:], 1)) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(36, 16, 16, 64), (68, 32, 8, 128), (32, 32, 8, 64), (132, 64, 8, 64), (100, 24, 16, 64)])
