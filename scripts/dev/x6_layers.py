@@ -65,6 +65,8 @@ for cin, cout, hw in specs:
                 us = measure(plan, op, bufs, 1)
             except M._lib.MfviError:
                 continue
+            if lib.mfvi_plan_last_kernel(plan.handle, op, 2) != 3:
+                print("%d->%d @%d bwd_weight bf16x6 cof=%d tb=%d: not served" % (cin, cout, hw, cof, tb), flush=True); continue
             print("%d->%d @%d bwd_weight bf16x6 cof=%d tb=%d: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak, %.3f of 2.5 PF / 6)" % (cin, cout, hw, cof, tb, us, tf(us), tf(us) / 157.3, tf(us) / (2500.0 / 6)), flush=True)
     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 2, base))
     # forward: autotuned kernel, the row-phase fp32 kernel, the bf16x6 kernel (csrc/conv_x6.hip, tune bit 25)
@@ -77,5 +79,7 @@ for cin, cout, hw in specs:
             us = measure(plan, op, bufs, 0)
         except M._lib.MfviError as e:
             print("fwd bf16x6 mf=%d: not served (%s)" % (mf, e)); continue
+        if lib.mfvi_plan_last_kernel(plan.handle, op, 0) != 3:
+            print("%d->%d @%d fwd        bf16x6 mf=%d T=%d: not served (fell back to kernel family %d)" % (cin, cout, hw, mf, T, lib.mfvi_plan_last_kernel(plan.handle, op, 0)), flush=True); continue
         print("%d->%d @%d fwd        bf16x6 mf=%d sr=8 T=%d: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak, %.3f of 2.5 PF / 6)" % (cin, cout, hw, mf, T, us, tf(us), tf(us) / 157.3, tf(us) / (2500.0 / 6)), flush=True)
     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, basef))
