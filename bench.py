@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: FP32 vector == FP32-input MFMA peak
+BF16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak; a bf16x6 kernel spends 6 bf16 instructions per fp32 product: ceiling 2500 / 6
 PASS_NAMES = {0: "fwd", 1: "bwd_weight", 2: "bwd_data", 3: "fold", 4: "concat_bwd", 5: "grad_finalize", 6: "sample_weights"}
 
 # hyper-parameters: test_configs/mfvi_{den,sr,ct}.json:5,9,15-18 of the reference; inpainting: configs/mfvi_inp.json
@@ -437,8 +438,21 @@ def main():
         try:
             from mfvi_dip_mia_amd import _lib as L_
             fam = lambda i, w: L_.lib().mfvi_plan_last_kernel(eng.plan.handle, i, w)
-            res["bf16x6_kernels"] = ["%s:%s" % (n_, conv_cost(eng.prog, i, 1)["desc"]) for i, o_ in enumerate(eng.prog.ops) if o_["type"] == 1
-                                     for w, n_ in ((0, "fwd"), (1, "bwd_data"), (2, "bwd_weight")) if fam(i, w) == 3]
+            x6 = []
+            for i, o_ in enumerate(eng.prog.ops):
+                if o_["type"] != 1:
+                    continue
+                for which, ps_, n_ in ((0, 0, "fwd"), (1, 2, "bwd_data"), (2, 1, "bwd_weight")):       # (family query index, profile pass id)
+                    if fam(i, which) != 3:
+                        continue
+                    c = conv_cost(eng.prog, i, eng.chunk)
+                    e_ = {"kernel": "%s:%s" % (n_, c["desc"])}
+                    if (i, ps_) in by:       # duration alone on the chip, from the untimed instrumented iteration (side stream off)
+                        ms1 = by[(i, ps_)] / n_launch
+                        tf = c["flops"] / ms1 / 1e9
+                        e_.update(alone_ms=ms1, tflops=tf, frac_of_f32_mfma_peak=tf / F32_PEAK_TFLOPS, frac_of_bf16_peak_over_6=tf / (BF16_PEAK_TFLOPS / 6.0))
+                    x6.append(e_)
+            res["bf16x6_kernels"] = x6
         except Exception:
             res["bf16x6_kernels"] = None
         if strong_extra:

@@ -152,6 +152,22 @@ __device__ __forceinline__ bf16_t f32_to_bf16_sr(float f, uint32_t r16)
     return (bf16_t)((u + (r16 & 0xffffu)) >> 16);
 }
 
+// bf16x6 kernels (conv_bww_x6.hip, conv_x6.hip): two fp32 values -> three packed bf16 pairs (low half = first value), a = h + m + l
+// exactly (round-to-nearest-even pieces of 8 significand bits: what is left after two steps has at most 8 bits), |m| <= 2^-8 |a|,
+// |l| <= 2^-16 |a|, so the three products the kernels drop (m l, l m, l l) stay below 2^-23 |a b|.  v_cvt_pk_bf16_f32 rounds and packs a
+// pair in one instruction: 11 VALU operations per pair, the same as a truncating split (which would leave 2^-21).
+typedef __bf16 mfvi_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mfvi_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_bf16x3(float a0, float a1, unsigned& h, unsigned& m, unsigned& l)
+{
+    const mfvi_f32x2 a = {a0, a1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(a, mfvi_bf16x2));
+    const mfvi_f32x2 r = {a0 - __uint_as_float(h << 16), a1 - __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, mfvi_bf16x2));
+    const mfvi_f32x2 t = {r.x - __uint_as_float(m << 16), r.y - __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(t, mfvi_bf16x2));
+}
+
 // torch.nn.functional.softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }

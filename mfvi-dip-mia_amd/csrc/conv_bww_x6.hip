@@ -4,8 +4,8 @@
 //   ReflectionPad2d(1) of models/common.py:100-135), the same GEMM as conv_bww_mfma.hip with the PIXEL index as reduction dimension.
 //
 // gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the rate of v_mfma_f32_16x16x32_bf16.  Every fp32 operand is the exact sum of three bf16
-// pieces, a = a_h + a_m + a_l (8 significand bits each, formed by the staging waves with two and / subtract pairs), and
-//   a * b = a_h b_h + a_h b_m + a_m b_h + a_m b_m + a_h b_l + a_l b_h  (+ terms below 2^-24 |a b|, dropped)
+// pieces, a = a_h + a_m + a_l (8 significand bits each, formed by the staging waves with v_cvt_pk_bf16_f32 and two subtractions), and
+//   a * b = a_h b_h + a_h b_m + a_m b_h + a_m b_m + a_h b_l + a_l b_h  (+ terms below 2^-23 |a b|, dropped)
 // is six bf16 matrix instructions with fp32 accumulation in place of eight fp32 ones: 96 instead of 256 matrix cycles for the same
 // 16 x 16 x 32 block of multiply-adds.  scripts/micro/bf16x6.hip (profiles/r03_bf16x6_micro.txt): error against fp64 3.7e-7 sum|a b|
 // at K = 4096 (the fp32 instruction: 3.5e-7), 370-400 TFLOP/s fp32-equivalent, two VALU fillers per matrix instruction for free.
@@ -40,25 +40,16 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// four floats -> three packed bf16 quads (h, m, l), a = h + m + l exactly: truncation keeps the top 8 significand bits, the remainder is
-// exact in fp32, twice; what is left after two steps has at most 8 bits
+// four floats -> three packed bf16 quads (h, m, l), a = h + m + l exactly (common.h, split_pair_bf16x3)
 __device__ __forceinline__ void split4(const float (&e)[4], u32x2& h, u32x2& m, u32x2& l)
 {
 #ifdef X6_DBG_NOSPLIT
     h.x = __float_as_uint(e[0]); h.y = __float_as_uint(e[1]); m.x = __float_as_uint(e[2]); m.y = __float_as_uint(e[3]); l = h; return;
 #endif
-    unsigned hh[4], mm[4], ll[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hh[i] = __float_as_uint(e[i]) & 0xffff0000u;
-        const float r = e[i] - __uint_as_float(hh[i]);
-        mm[i] = __float_as_uint(r) & 0xffff0000u;
-        ll[i] = __float_as_uint(r - __uint_as_float(mm[i]));
-    }
-    // bytes 2, 3 of the first source into the low half, bytes 2, 3 of the second into the high half
-    h.x = __builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u); h.y = __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u);
-    m.x = __builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u); m.y = __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u);
-    l.x = __builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u); l.y = __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u);
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair_bf16x3(e[0], e[1], h0, m0, l0);
+    split_pair_bf16x3(e[2], e[3], h1, m1, l1);
+    h = (u32x2){h0, h1}; m = (u32x2){m0, m1}; l = (u32x2){l0, l1};
 }
 
 // BW = band width in pixels: 64 (stage = 2 padded rows x 2 segments of 32 pixels) or 32 (maps 32 wide: stage = 4 padded rows x 1 segment)

@@ -37,23 +37,11 @@ __device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// eight floats -> three packed bf16 octets (h, m, l), a = h + m + l exactly (conv_bww_x6.hip, split4)
+// eight floats -> three packed bf16 octets (h, m, l), a = h + m + l exactly (common.h, split_pair_bf16x3)
 __device__ __forceinline__ void split8(const float (&e)[8], u32x4& h, u32x4& m, u32x4& l)
 {
-    unsigned hh[8], mm[8], ll[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        hh[i] = __float_as_uint(e[i]) & 0xffff0000u;
-        const float r = e[i] - __uint_as_float(hh[i]);
-        mm[i] = __float_as_uint(r) & 0xffff0000u;
-        ll[i] = __float_as_uint(r - __uint_as_float(mm[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = __builtin_amdgcn_perm(hh[2 * i + 1], hh[2 * i], 0x07060302u);
-        m[i] = __builtin_amdgcn_perm(mm[2 * i + 1], mm[2 * i], 0x07060302u);
-        l[i] = __builtin_amdgcn_perm(ll[2 * i + 1], ll[2 * i], 0x07060302u);
-    }
+    for (int i = 0; i < 4; ++i) { unsigned hh, mm, ll; split_pair_bf16x3(e[2 * i], e[2 * i + 1], hh, mm, ll); h[i] = hh; m[i] = mm; l[i] = ll; }
 }
 
 // ---- weight pieces: thread = one 16-byte unit (row, co, octet) of sample k -> three pieces ----

@@ -1,5 +1,6 @@
 // Microbenchmark: fp32 GEMM on the bf16 matrix cores by a three-way operand split ("bf16x6").
-//   a = a_h + a_m + a_l (three bf16 pieces, exact), a*b ~= a_h b_h + a_h b_m + a_m b_h + a_m b_m + a_h b_l + a_l b_h   (dropped: 2^-24 terms)
+//   a = a_h + a_m + a_l (three bf16 pieces, exact), a*b ~= a_h b_h + a_h b_m + a_m b_h + a_m b_m + a_h b_l + a_l b_h
+//   (dropped: m l + l m + l l <= 2^-23 |a b| with round-to-nearest pieces — what the kernels use — 2^-21 with truncated pieces)
 // on v_mfma_f32_16x16x32_bf16 (16 cycles per instruction per SIMD, 16x the fp32 MFMA rate): six instructions replace eight
 // v_mfma_f32_16x16x4_f32 (256 cycles) -> 2.67x the fp32 matrix peak at fp32 accuracy.
 // Part 1: operand layout + accuracy against fp64 (fp32 MFMA, x6 with RNE pieces, x6 with truncated pieces, x3).
