@@ -30,6 +30,8 @@
  *      MFVI_X6=0               heuristic tilings (no autotune): backward-weight never on the bf16x6 kernel (conv_bww_x6.hip); the autotuner's
  *                              candidates and explicit tilings (w = 11; forward: tune bit 25, conv_x6.hip) are not affected
  *      MFVI_TUNE_RP=mf,r,T[,rem[,ks]]  force one row-phase tiling where the plan holds none
+ *      MFVI_RP_INTERLEAVE=0    row-phase kernels: a block takes a contiguous run of T tiles (default: tiles b, b + nx, b + 2 nx, ... so that the
+ *                              blocks of an XCD work on adjacent tiles at every moment: halo rows and straddled cache lines are L2 hits)
  *      MFVI_PHASE=0            stride-2 backward-data: zero-stuffed formulation instead of the phase decomposition
  *      MFVI_FOLD_FUSION=0      1x1 backward-data writes the padded gradient + a finalize_dx launch (fold not fused)
  *      MFVI_FOLD_FUSION3=0     the same for the 3x3 stride-1 layers

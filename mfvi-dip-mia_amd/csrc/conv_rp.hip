@@ -45,7 +45,7 @@ struct RpArgs {
     const float* w; long long wstride;     // weights of sample k at w + k*wstride
     OutDesc out;                           // MODE 0
     float* fga; long long fga_sstride; double* fbsums;      // MODE 1: gradient wrt the BN output of the input tensor, its BN-backward sums (or nullptr)
-    int tiles_x, n_tiles, tiles_per_block;
+    int tiles_x, n_tiles, tiles_per_block, interleave;      // interleave: block b takes tiles b, b + nx, b + 2 nx, ... (see launch_rp)
     int nx, ny, nz;                        // logical grid (tile groups, output-channel tiles, samples), launched 1-D
 };
 
@@ -133,9 +133,15 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         }
     }
 
-    const int tile_begin = bx * A.tiles_per_block, tile_end = min(A.n_tiles, tile_begin + A.tiles_per_block);
-    if (tile_begin >= tile_end) return;
-    const int n_iters = (tile_end - tile_begin) * n_chunks;
+    // the block's tiles by ordinal j: TILE(j).  Interleaved (default): b, b + nx, ... — at every moment the blocks of an XCD band work on
+    // ADJACENT tiles, whose halo rows and the cache lines the 66-pixel window rows straddle are then L2 hits (as with one tile per block);
+    // with a contiguous run of T tiles per block the neighbours ran T tiles apart in time and every window came from HBM again
+    // (36->16 @256^2, T = 8: 503 MB of reads per launch against 288 MB at T = 1; profiles/r03_rp_traffic_tilings.txt).
+    const int tstep = A.interleave ? A.nx : 1, tfirst = A.interleave ? bx : bx * A.tiles_per_block;
+    const int n_my = A.interleave ? (A.n_tiles - bx + A.nx - 1) / A.nx : min(A.tiles_per_block, A.n_tiles - tfirst);
+    if (n_my <= 0) return;
+    auto TILE = [&](int j) { return tfirst + j * tstep; };
+    const int n_iters = n_my * n_chunks;
 
     if (producer) {
         // ======================= producer waves =======================
@@ -357,23 +363,24 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         };
 
         // running (tile, chunk) of the stage being fetched: two stages ahead of the consumers
-        int ftile = tile_begin, fc = 0;
+        int ftile = 0, fc = 0;                            // (ordinal of the tile being fetched)
         auto advance = [&]() { fc += 4 * KS; if (fc >= RED) { fc = 0; ++ftile; return true; } return false; };
-        set_tile(ftile); prefetch(fc); wfetch(fc);
+        set_tile(TILE(ftile)); prefetch(fc); wfetch(fc);
         __syncthreads();                                  // (S0) channel constants / bias visible
         store(fc, s_x[0]); wstore(s_w);
         int sc = 0;                                       // chunk base of the stage held in registers (stored next)
-        if (n_iters > 1) { if (advance()) set_tile(ftile); sc = fc; prefetch(fc); wfetch(fc); }
+        if (n_iters > 1) { if (advance()) set_tile(TILE(ftile)); sc = fc; prefetch(fc); wfetch(fc); }
         lds_barrier();                                    // (A) chunk 0 published
         RP_T(p_loop0); RP_ACC(8, p_loop0 - t_entry);
-        int fci = 0, fdt = tile_begin - 1;                // stage index inside the consumers' current tile; tile whose dump is being folded
+        int fci = 0, fdt = -1;                            // stage index inside the consumers' current tile; ordinal of the tile whose dump is being folded
         for (int it = 0; it < n_iters; ++it) {
             RP_T(p0);
             // a part's raw-x loads are issued at the head of its stage and fly while the stage is staged.  (Issuing them one stage ahead —
             // they do not depend on the dump — was built and measured: 0 ... -5 %, NOTES.)
             constexpr std::integral_constant<int, 0> p0c{}; constexpr std::integral_constant<int, 1> p1c{}; constexpr std::integral_constant<int, 2> p2c{};
-            const bool fold_now = MODE == 1 && fdt >= tile_begin && fci < FP;
-            if (fold_now) { if (fci == 0) fold_fetch(fdt, p0c); else if (fci == 1) fold_fetch(fdt, p1c); else fold_fetch(fdt, p2c); }
+            const bool fold_now = MODE == 1 && fdt >= 0 && fci < FP;
+            const int fdtile = TILE(max(fdt, 0));
+            if (fold_now) { if (fci == 0) fold_fetch(fdtile, p0c); else if (fci == 1) fold_fetch(fdtile, p1c); else fold_fetch(fdtile, p2c); }
             if (it + 1 < n_iters) {
 #ifdef RP_PROF
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -381,10 +388,10 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                 RP_T(p1); RP_ACC(9, p1 - p0);                                   // waiting for the prefetched loads
                 store(sc, s_x[(it + 1) & 1]); wstore(s_w + ((it + 1) & 1) * WCH);
                 RP_T(p2); RP_ACC(10, p2 - p1);                                  // transform + LDS writes
-                if (it + 2 < n_iters) { if (advance()) set_tile(ftile); sc = fc; prefetch(fc); wfetch(fc); }
+                if (it + 2 < n_iters) { if (advance()) set_tile(TILE(ftile)); sc = fc; prefetch(fc); wfetch(fc); }
                 RP_T(p3); RP_ACC(11, p3 - p2);                                  // issuing the next loads
             }
-            if (fold_now) { if (fci == 0) fold_do(fdt, p0c); else if (fci == 1) fold_do(fdt, p1c); else fold_do(fdt, p2c); }
+            if (fold_now) { if (fci == 0) fold_do(fdtile, p0c); else if (fci == 1) fold_do(fdtile, p1c); else fold_do(fdtile, p2c); }
             RP_T(p4);
             lds_barrier();
             RP_T(p5); RP_ACC(12, p5 - p4);                                      // barrier wait
@@ -392,7 +399,8 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         }
         if constexpr (MODE == 1) {      // the block's last tile, then this thread's BN-backward partials (channel of (wave, j): wave-uniform)
             constexpr std::integral_constant<int, 0> p0c{}; constexpr std::integral_constant<int, 1> p1c{}; constexpr std::integral_constant<int, 2> p2c{};
-            fold_fetch(tile_end - 1, p0c); fold_do(tile_end - 1, p0c); fold_fetch(tile_end - 1, p1c); fold_do(tile_end - 1, p1c); fold_fetch(tile_end - 1, p2c); fold_do(tile_end - 1, p2c);
+            const int tlast = TILE(n_my - 1);
+            fold_fetch(tlast, p0c); fold_do(tlast, p0c); fold_fetch(tlast, p1c); fold_do(tlast, p1c); fold_fetch(tlast, p2c); fold_do(tlast, p2c);
             if (fuse_sums) {
 #pragma unroll
                 for (int j = 0; j < NIT; ++j) {
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             RP_T(c_loop0); RP_ACC(0, c_loop0 - t_entry);
             for (int it = 0; it < n_iters; ++it) {
                 RP_T(c0);
-                const int tile = tile_begin + it / n_chunks, ci = it % n_chunks;
+                const int tile = TILE(it / n_chunks), ci = it % n_chunks;
                 const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
                 const int row0 = py0 + wv * R;                               // first image row of this wave
                 if (ci == 0) {
@@ -602,6 +610,7 @@ int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
     A.tiles_x = g.W / 64;
     A.n_tiles = A.tiles_x * (g.H / Cfg::TH);
     A.tiles_per_block = T;
+    { static const int il = [] { const char* e = getenv("MFVI_RP_INTERLEAVE"); return !(e && e[0] == '0'); }(); A.interleave = il; }
     A.nx = (A.n_tiles + T - 1) / T; A.ny = REM ? (MOUT - 4) / CT : (MOUT + CT - 1) / CT; A.nz = n_samples;
     constexpr int WCH = KS * (MF * 4 * 16 * 12 + (REM ? 4 * 4 * 12 : 0));
     const size_t dyn = sizeof(float) * 2 * WCH + sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(RpBwd) * (size_t)((g.Cout + 3) & ~3);
