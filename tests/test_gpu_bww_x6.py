@@ -45,11 +45,12 @@ def test_x6_backward_weight_against_fp32_mfma(M, shape):
     assert tried == 4
 
 
-@pytest.mark.parametrize("case", [(36, 16, 8, 64), (16, 32, 12, 128), (36, 32, 10, 32)])
+@pytest.mark.parametrize("case", [(36, 16, 8, 64, 2), (16, 32, 12, 128, 2), (36, 32, 10, 32, 2), (68, 16, 6, 64, 3), (32, 40, 4, 96, 1)])
 def test_x6_backward_weight_against_float64(M, case):
-    """Single layer from the plan's input (no BatchNorm on either side): d mu / d rho against the gradient restated in float64."""
-    cin, cout, H, W = case
-    seed, step, k0, n = 3000 + cin + cout, 5, 0, 2
+    """Single layer from the plan's input (no BatchNorm on either side, the input shared by all samples): d mu / d rho against the gradient
+    restated in float64; one, two and three samples (launch orders with and without the XCD banding)."""
+    cin, cout, H, W, n = case
+    seed, step, k0 = 3000 + cin + cout, 5, 0
     P = M.Program()
     zin = P.tensor(cin, H, W); out = P.tensor(cout, H, W); P.conv(zin, out, 3, 1)
     plan = P.compile(zin, out, max_samples=n)
