@@ -64,9 +64,13 @@ __device__ __forceinline__ unsigned long long rp_now() { unsigned long long t; a
 // (chan_bwd's  c1 * (ga - c2 - xhat * c3)  with the products of the channel constants formed once per block)
 struct RpBwd { float mean, qc, c1, k2; };
 
-template <int R, int MODE>
+// W32 (maps exactly 32 wide, forward only): the 64 "pixels" of a strip are TWO image rows side by side — lanes n = 0..7 the quads of image
+// row y, lanes 8..15 those of image row y + TH (the tile is 2 TH image rows tall) — so the vertical taps are +-1 window row for both
+// halves; a window row is [34 columns of the upper half + 2 pad | 34 columns of the lower half + 2 pad] = 18 quads, and a lane's six floats
+// start at 4 (n + (n >> 3)).  Both halves carry both image borders.
+template <int R, int MODE, bool W32 = false>
 struct RpCfg {
-    static constexpr int TH = 4 * R, WROWS = TH + 2, NQ = 17, PITCH = 4 * NQ;       // 66 window columns -> 17 quads
+    static constexpr int TH = 4 * R, WROWS = TH + 2, NQ = W32 ? 18 : 17, PITCH = 4 * NQ;       // 66 window columns -> 17 quads
     // MODE 1: two extra rows per channel plane hold the row part of the reflection adjoint (S1 = dy[2] + dy[0] for image row 1,
     // S2 = dy[H-3] + dy[H-1] for image row H-2; see the kernel's header)
     static constexpr int PROWS = WROWS + (MODE == 1 ? 2 : 0);
@@ -76,12 +80,13 @@ struct RpCfg {
 
 // MINW: minimum waves per SIMD the register allocation must allow (4 = 128 VGPRs = two 512-thread blocks per CU)
 // KS: 4-channel k-steps per stage (one barrier per stage: a stage boundary costs ~800 cycles of matrix time, see NOTES)
-template <int MODE, int MF, int R, bool REM, int KS, int MINW>
+template <int MODE, int MF, int R, bool REM, int KS, int MINW, bool W32 = false>
 __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
 {
     static_assert(!REM || MODE == 1, "remainder channels: backward-data only");
+    static_assert(!W32 || MODE == 0, "32-wide maps: forward only");
     static_assert(MODE == 0 || R <= 2, "backward-data: image rows 1 / H-2 must be the last / first row of their wave");
-    using Cfg = RpCfg<R, MODE>;
+    using Cfg = RpCfg<R, MODE, W32>;
     constexpr int TH = Cfg::TH, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, NITEM = Cfg::NITEM, NV = Cfg::NV;
     constexpr int CT = 16 * MF, CTX = CT + (REM ? 4 : 0);
     constexpr int WFR = 4 * 16 * 12;                           // floats of one output fragment's weight chunk: [k 4][m 16][ky 3][4]
@@ -162,13 +167,14 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         bool sp1 = false, sp2 = false;      // MODE 1: the tile of the stage in registers holds image row 1 / H-2
         float4 xv[KS][NV], yv[MODE == 1 ? KS : 1][MODE == 1 ? NV : 1];
         auto set_tile = [&](int tile) {
-            const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+            const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
             flags = 0; anyf = 0;
             sp1 = MODE == 1 && py0 == 0; sp2 = MODE == 1 && py0 + TH == H;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int q = min(lane + 64 * j, NITEM - 1), iy = q / Cfg::NQ, v = q - iy * Cfg::NQ;
                 int gy = py0 - 1 + iy, gx = px0 - 1 + 4 * v; unsigned flag = 0;
+                if (W32) { const int sub = v >= 9 ? 1 : 0; gy += sub * TH; gx = -1 + 4 * (v - 9 * sub); }      // lower half: image rows TH further down
                 if (MODE == 0) { gy = reflect_idx(gy, H); gy = min(max(gy, 0), H - 1); }
                 else if (gy < 0 || gy >= H) { flag = 3; gy = 0; }
                 if (gx < 0) { if (flag == 0) flag = 1; gx = 0; }
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         // ======================= consumer waves =======================
         const bool do_stats = MODE == 0 && A.out.stats != nullptr;
         if (do_stats) for (int q = lane; q < CTX; q += 64) { s_red[wv][q][0] = 0.0; s_red[wv][q][1] = 0.0; }
-        const int xb = l4 * PLANE + (wv * R) * PITCH + 4 * l15;          // this lane's six-float window read, row 0 of the wave
+        const int xb = l4 * PLANE + (wv * R) * PITCH + 4 * (l15 + (W32 ? l15 >> 3 : 0));      // this lane's six-float window read, row 0 of the wave
         const int wb = (l4 * 16 + l15) * 12;                             // weights of (k = l4, m = l15)
         const int wxb = MF * WFR + (l4 * 4 + (lane & 3)) * 12;           // REM: A operand of the 4x4x1 instruction = w[extra channel lane & 3][k = l4]
         __syncthreads();                                  // (S0)
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             for (int it = 0; it < n_iters; ++it) {
                 RP_T(c0);
                 const int tile = TILE(it / n_chunks), ci = it % n_chunks;
-                const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
                 const int row0 = py0 + wv * R;                               // first image row of this wave
                 if (ci == 0) {
     #pragma unroll
@@ -525,7 +531,8 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                                     const float bi = s_bias[ml];
                                     const float v0 = acc[f][r][0][q] + bi, v1 = acc[f][r][1][q] + bi, v2 = acc[f][r][2][q] + bi, v3 = acc[f][r][3][q] + bi;
                                     if (ml < mt) {
-                                        *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(v0, v1, v2, v3);
+                                        if constexpr (W32) *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r + (l15 >> 3) * TH) * W + 4 * (l15 & 7)) = make_float4(v0, v1, v2, v3);
+                                        else *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(v0, v1, v2, v3);
                                         fs[q] += (v0 + v1) + (v2 + v3);
                                         fq[q] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, fq[q]))));
                                     }
@@ -595,20 +602,20 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
     }
 }
 
-template <int MODE, int MF, int R, bool REM, int KS>
+template <int MODE, int MF, int R, bool REM, int KS, bool W32 = false>
 int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
 {
-    using Cfg = RpCfg<R, MODE>;
+    using Cfg = RpCfg<R, MODE, W32>;
     const ConvGeom& g = A.g;
     const int MOUT = MODE == 0 ? g.Cout : g.Cin;
     constexpr int CT = 16 * MF;
-    if (g.H % Cfg::TH) return -3;
+    if (g.H % (W32 ? 2 * Cfg::TH : Cfg::TH)) return -3;
     const int RED = MODE == 0 ? g.Cin : g.Cout;
     if (RED % (4 * KS)) return -3;
     if (MODE == 1 && RED / (4 * KS) < 4) return -3;       // the fold of a tile rides on stages 0..2 of the next one
     if (REM && !((MOUT & 15) == 4 && (MOUT - 4) % CT == 0)) return -3;
-    A.tiles_x = g.W / 64;
-    A.n_tiles = A.tiles_x * (g.H / Cfg::TH);
+    A.tiles_x = W32 ? 1 : g.W / 64;
+    A.n_tiles = W32 ? g.H / (2 * Cfg::TH) : A.tiles_x * (g.H / Cfg::TH);
     A.tiles_per_block = T;
     { static const int il = [] { const char* e = getenv("MFVI_RP_INTERLEAVE"); return !(e && e[0] == '0'); }(); A.interleave = il; }
     A.nx = (A.n_tiles + T - 1) / T; A.ny = REM ? (MOUT - 4) / CT : (MOUT + CT - 1) / CT; A.nz = n_samples;
@@ -616,7 +623,7 @@ int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
     const size_t dyn = sizeof(float) * 2 * WCH + sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(RpBwd) * (size_t)((g.Cout + 3) & ~3);
     constexpr int MINW = 4;
     mfvi_tl_family = 2;
-    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, KS, MINW>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
+    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, KS, MINW, W32>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
     return (int)hipGetLastError();
 }
 
@@ -627,6 +634,14 @@ int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
     const int mf = tune & 255, r = (tune >> 8) & 15, rem = (tune >> 12) & 1, ks = max(1, (tune >> 13) & 7), T = max(1, (tune >> 16) & 255);
 #define RP_GO2(MF_, R_, KS_) if (mf == MF_ && r == R_ && ks == KS_) { if constexpr (MODE == 1) { if (rem) return launch_rp<MODE, MF_, R_, true, KS_>(A, T, n_samples, st); } if (rem) return -3; return launch_rp<MODE, MF_, R_, false, KS_>(A, T, n_samples, st); }
 #define RP_GO(MF_, R_) RP_GO2(MF_, R_, 1)      /* two k-steps per stage (KS = 2) built and measured: no gain, register spills in backward-data; not instantiated */
+    if constexpr (MODE == 0) {
+        if (A.g.W == 32) {      // maps 32 wide: two image rows per 64-pixel strip
+#define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1 && !rem) return launch_rp<0, MF_, R_, false, 1, true>(A, T, n_samples, st);
+            RP_GO32(1, 1) RP_GO32(1, 2) RP_GO32(2, 1) RP_GO32(2, 2) RP_GO32(4, 1) RP_GO32(1, 4)
+#undef RP_GO32
+            return -3;
+        }
+    }
     RP_GO(1, 1) RP_GO(1, 2) RP_GO(2, 1)
     if constexpr (MODE == 0) { RP_GO(2, 2) RP_GO2(4, 1, 1) RP_GO2(1, 4, 1) }       // backward-data: rows 1 / H-2 must be the last / first row of their wave (R <= 2); its out tile keeps (2, 2) / (4, 1) at one block per CU
 #undef RP_GO
@@ -639,7 +654,7 @@ int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
 // Returns -2 when the shape is not served by the row-phase kernels, -3 when the tiling is not valid for it.
 int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st)
 {
-    if (g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3) || (g.Cin & 3) || (g.w_off & 3) || g.Cin > MFVI_MAX_C) return -2;
+    if (g.ks != 3 || g.stride != 1 || ((g.W & 63) && g.W != 32) || (g.H & 3) || (g.Cin & 3) || (g.w_off & 3) || g.Cin > MFVI_MAX_C) return -2;
     if ((in.sstride & 3) || ((uintptr_t)in.data & 15) || (out.sstride & 3) || ((uintptr_t)out.data & 15)) return -2;
     if (in.act & MFVI_ACT_SQUARE) return -2;                                          // variance convolution of the LRT layers: round-2 kernels
     if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 29)) return -2;          // 32-bit element offsets per sample, two flag bits
@@ -666,7 +681,7 @@ int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, 
 int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
 {
     static const int on = [] { const char* e = getenv("MFVI_RP"); return !(e && e[0] == '0'); }();
-    if (!on || g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3)) return 0;
+    if (!on || g.ks != 3 || g.stride != 1 || ((g.W & 63) && !(g.W == 32 && mode == 0 && (g.H & 7) == 0)) || (g.H & 3)) return 0;
     static const int forced = [] { int mf = 0, r = 0, T = 1, rem = 0, ks = 1; const char* e = getenv("MFVI_TUNE_RP"); if (e) sscanf(e, "%d,%d,%d,%d,%d", &mf, &r, &T, &rem, &ks); return mf > 0 ? (mf | r << 8 | (rem & 1) << 12 | (ks & 7) << 13 | T << 16) : 0; }();
     if (forced) return forced | MFVI_TUNE_RP;
     const int MOUT = mode == 0 ? g.Cout : g.Cin;

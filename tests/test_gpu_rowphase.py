@@ -115,3 +115,48 @@ def test_rowphase_small_nets_against_oracle(M, kw):
     assert relerr(host(dmu), r_dmu) < 2e-4
     assert relerr(host(drho), r_drho) < 2e-4
     assert relerr(host(dbn), r_dbn) < 2e-4
+
+
+@pytest.mark.parametrize("case", [(16, 16, 16, 32), (36, 16, 8, 32), (64, 64, 32, 32), (20, 48, 16, 32), (132, 32, 16, 32)])
+def test_rowphase_forward_on_32_wide_maps(M, case):
+    """Maps exactly 32 wide: two image rows side by side in the 64-pixel strip (conv_rp.hip, W32) — both halves carry both image borders, the
+    lower half sits TH rows further down.  Single layer against the oracle's convolution, then behind BatchNorm + LeakyReLU against the
+    round-2 tiling (output, BN statistics of the output through the following layer, gradients)."""
+    cin, cout, H, W = case
+    seed, step, k0, n = 2300 + cin + cout, 4, 1, 2
+    P = M.Program()
+    zin = P.tensor(cin, H, W); out = P.tensor(cout, H, W); P.conv(zin, out, 3, 1)
+    plan = P.compile(zin, out, max_samples=n)
+    nw = cout * cin * 9
+    mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+    x = O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W)
+    d_mu, d_rho, d_x = dev(mu), dev(rho), dev(x)
+    bn = torch.zeros(1, device="cuda")
+    lib = M._lib.lib()
+    tried = 0
+    for mf, r, T in [(1, 1, 1), (1, 2, 1), (2, 1, 2), (2, 2, 1), (4, 1, 1), (1, 4, 1), (1, 1, 3)]:
+        if H % (8 * r) or (mf > 1 and cout < 16 * mf and cout % 16 == 0 and False):
+            continue
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, enc_rp(mf, r, T)))
+        y = plan.forward(d_mu, d_rho, bn, d_x, seed, step, k0, n)
+        if lib.mfvi_plan_last_kernel(plan.handle, 0, 0) != 2:
+            continue          # tiling not valid for the shape: fell back
+        tried += 1
+        yh = host(y)
+        for i in range(n):
+            ew = O.eps(seed, step, k0 + i, 0, 0, nw); eb = O.eps(seed, step, k0 + i, 0, 1, cout)
+            w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, 3, 3); b = O.reparam(mu[nw:], rho[nw:], eb)
+            assert relerr(yh[i], O.conv_fwd(x, w, b, 1)) < 2e-6, ("fwd", mf, r, T, i)
+    assert tried >= 3
+    # behind BatchNorm + LeakyReLU, with the BN statistics of the output feeding the next layer and the backward pass
+    P2, plan2, zin2, out2 = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    M._lib.check(lib.mfvi_plan_set_tune(plan2.handle, 1, 0, enc(1, 8, 1)))
+    ref = _run_plan(plan2, P2, seed, n, z, dout)
+    M._lib.check(lib.mfvi_plan_set_tune(plan2.handle, 1, 0, enc_rp(1, 1, 1)))
+    got = _run_plan(plan2, P2, seed, n, z, dout)
+    assert lib.mfvi_plan_last_kernel(plan2.handle, 1, 0) == 2
+    assert relerr(got[0], ref[0]) < 1e-6
+    for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+        assert relerr(a, b) < 2e-5, name
