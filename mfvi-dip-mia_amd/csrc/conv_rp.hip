@@ -64,7 +64,7 @@ __device__ __forceinline__ unsigned long long rp_now() { unsigned long long t; a
 // (chan_bwd's  c1 * (ga - c2 - xhat * c3)  with the products of the channel constants formed once per block)
 struct RpBwd { float mean, qc, c1, k2; };
 
-// W32 (maps exactly 32 wide, forward only): the 64 "pixels" of a strip are TWO image rows side by side — lanes n = 0..7 the quads of image
+// W32 (maps exactly 32 wide): the 64 "pixels" of a strip are TWO image rows side by side — lanes n = 0..7 the quads of image
 // row y, lanes 8..15 those of image row y + TH (the tile is 2 TH image rows tall) — so the vertical taps are +-1 window row for both
 // halves; a window row is [34 columns of the upper half + 2 pad | 34 columns of the lower half + 2 pad] = 18 quads, and a lane's six floats
 // start at 4 (n + (n >> 3)).  Both halves carry both image borders.
@@ -84,7 +84,6 @@ template <int MODE, int MF, int R, bool REM, int KS, int MINW, bool W32 = false>
 __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
 {
     static_assert(!REM || MODE == 1, "remainder channels: backward-data only");
-    static_assert(!W32 || MODE == 0, "32-wide maps: forward only");
     static_assert(MODE == 0 || R <= 2, "backward-data: image rows 1 / H-2 must be the last / first row of their wave");
     using Cfg = RpCfg<R, MODE, W32>;
     constexpr int TH = Cfg::TH, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, NITEM = Cfg::NITEM, NV = Cfg::NV;
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         auto set_tile = [&](int tile) {
             const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
             flags = 0; anyf = 0;
-            sp1 = MODE == 1 && py0 == 0; sp2 = MODE == 1 && py0 + TH == H;
+            sp1 = MODE == 1 && py0 == 0; sp2 = MODE == 1 && py0 + (W32 ? 2 : 1) * TH == H;      // (W32: image row H - 2 sits in the lower half of the last tile)
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int q = min(lane + 64 * j, NITEM - 1), iy = q / Cfg::NQ, v = q - iy * Cfg::NQ;
@@ -321,20 +320,21 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             constexpr int part = decltype(part_c)::value;
             if constexpr (MODE == 1) {
                 if (!fuse_sums) return;
-                const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
                 const float* __restrict__ xq = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HW + py0 * W + px0;
                 int tl = t; asm volatile("" : "+v"(tl));       // the items' index arithmetic is recomputed here, not hoisted over the stage loop (27 registers)
 #pragma unroll
                 for (int j = part; j < NIT; j += FP) {
                     const int idx = tl + 256 * j, ch = idx / (TH * 16), rw = (idx >> 4) % TH, v = idx & 15;
-                    fxr[j / FP] = ch < mtx ? *reinterpret_cast<const float4*>(xq + ch * HW + rw * W + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int po = W32 ? (rw + (v >> 3) * TH) * W + 4 * (v & 7) : rw * W + 4 * v;      // (W32: float4 column v >= 8 = the lower half)
+                    fxr[j / FP] = ch < mtx ? *reinterpret_cast<const float4*>(xq + ch * HW + po) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };
         auto fold_do = [&](int tile, auto part_c) {
             constexpr int part = decltype(part_c)::value;
             if constexpr (MODE == 1) {
-                const int px0 = (tile % A.tiles_x) * 64, py0 = (tile / A.tiles_x) * TH;
+                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
                 float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * HW + py0 * W + px0;
                 const int xact = A.xin.act; const float xslope = A.xin.slope;
                 int tl = t; asm volatile("" : "+v"(tl));
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                                 for (int l = 0; l < 4; ++l) { fsum[j] += dd[l]; fxs[j] = __builtin_fmaf(dd[l], yy[l] - cf.mean, fxs[j]); }
                             }
                         }
-                        *reinterpret_cast<float4*>(o + ch * HW + rw * W + 4 * v) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                        *reinterpret_cast<float4*>(o + ch * HW + (W32 ? (rw + (v >> 3) * TH) * W + 4 * (v & 7) : rw * W + 4 * v)) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                     }
                 }
             }
@@ -472,9 +472,14 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
     #pragma unroll
                 for (int rr = 0; rr < R + 2; ++rr) {
                     int ro = rr * PITCH;
-                    if constexpr (MODE == 1) {          // wave-uniform: the spare window rows S1 / S2 stand in for dy[2] / dy[H-3] (header)
-                        if (rr == R + 1 && row0 + R - 1 == 1) ro = (Cfg::WROWS - wv * R) * PITCH;
-                        if (rr == 0 && row0 == H - 2) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
+                    if constexpr (MODE == 1) {          // the spare window rows S1 / S2 stand in for dy[2] / dy[H-3] (header): wave-uniform; W32: for the lanes of ONE half
+                        if constexpr (W32) {
+                            if (rr == R + 1 && row0 + R - 1 == 1 && l15 < 8) ro = (Cfg::WROWS - wv * R) * PITCH;
+                            if (rr == 0 && row0 + TH == H - 2 && l15 >= 8) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
+                        } else {
+                            if (rr == R + 1 && row0 + R - 1 == 1) ro = (Cfg::WROWS - wv * R) * PITCH;
+                            if (rr == 0 && row0 == H - 2) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
+                        }
                     }
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(sx + ro);
                     const f32x2 hi = *reinterpret_cast<const f32x2*>(sx + ro + 4);
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                 if constexpr (MODE == 1) {
                     // column part of the reflection adjoint: image column 1 (phase 1 of lane 0 in the leftmost tile) takes tap kx = 2 from
                     // win[3] + win[1]; column W-2 (phase 2 of lane 15 in the rightmost tile) takes tap kx = 0 from win[2] + win[4]
-                    const float ml = (px0 == 0 && l15 == 0) ? 1.f : 0.f, mr = (px0 + 64 == W && l15 == 15) ? 1.f : 0.f;
+                    const float ml = (W32 ? (l15 & 7) == 0 : (px0 == 0 && l15 == 0)) ? 1.f : 0.f, mr = (W32 ? (l15 & 7) == 7 : (px0 + 64 == W && l15 == 15)) ? 1.f : 0.f;
     #pragma unroll
                     for (int rr = 0; rr < R + 2; ++rr) { b[rr][6] = __builtin_fmaf(ml, b[rr][1], b[rr][3]); b[rr][7] = __builtin_fmaf(mr, b[rr][4], b[rr][2]); }
                 }
@@ -634,13 +639,17 @@ int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
     const int mf = tune & 255, r = (tune >> 8) & 15, rem = (tune >> 12) & 1, ks = max(1, (tune >> 13) & 7), T = max(1, (tune >> 16) & 255);
 #define RP_GO2(MF_, R_, KS_) if (mf == MF_ && r == R_ && ks == KS_) { if constexpr (MODE == 1) { if (rem) return launch_rp<MODE, MF_, R_, true, KS_>(A, T, n_samples, st); } if (rem) return -3; return launch_rp<MODE, MF_, R_, false, KS_>(A, T, n_samples, st); }
 #define RP_GO(MF_, R_) RP_GO2(MF_, R_, 1)      /* two k-steps per stage (KS = 2) built and measured: no gain, register spills in backward-data; not instantiated */
-    if constexpr (MODE == 0) {
-        if (A.g.W == 32) {      // maps 32 wide: two image rows per 64-pixel strip
+    if (A.g.W == 32) {      // maps 32 wide: two image rows per 64-pixel strip
+        if constexpr (MODE == 0) {
 #define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1 && !rem) return launch_rp<0, MF_, R_, false, 1, true>(A, T, n_samples, st);
             RP_GO32(1, 1) RP_GO32(1, 2) RP_GO32(2, 1) RP_GO32(2, 2) RP_GO32(4, 1) RP_GO32(1, 4)
 #undef RP_GO32
-            return -3;
+        } else {
+#define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1) { if (rem) return launch_rp<1, MF_, R_, true, 1, true>(A, T, n_samples, st); return launch_rp<1, MF_, R_, false, 1, true>(A, T, n_samples, st); }
+            RP_GO32(1, 1) RP_GO32(1, 2) RP_GO32(2, 1)
+#undef RP_GO32
         }
+        return -3;
     }
     RP_GO(1, 1) RP_GO(1, 2) RP_GO(2, 1)
     if constexpr (MODE == 0) { RP_GO(2, 2) RP_GO2(4, 1, 1) RP_GO2(1, 4, 1) }       // backward-data: rows 1 / H-2 must be the last / first row of their wave (R <= 2); its out tile keeps (2, 2) / (4, 1) at one block per CU
@@ -665,7 +674,7 @@ int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long 
 
 int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse)
 {
-    if (g.ks != 3 || g.stride != 1 || (g.W & 63) || (g.H & 3) || g.H < 4 || (g.Cin & 3) || (g.Cout & 3) || (g.w_off & 3) || g.Cout > MFVI_MAX_C || g.Cin > MFVI_MAX_C) return -2;
+    if (g.ks != 3 || g.stride != 1 || ((g.W & 63) && g.W != 32) || (g.H & 3) || g.H < 4 || (g.Cin & 3) || (g.Cout & 3) || (g.w_off & 3) || g.Cout > MFVI_MAX_C || g.Cin > MFVI_MAX_C) return -2;
     if (!fuse.ga || (fuse.ga_sstride & 3) || ((uintptr_t)fuse.ga & 15) || g.Cout < 16) return -2;      // the fold of a tile rides on stages 0..2 of the next one
     if ((gy.gstride & 3) || ((uintptr_t)gy.ga & 15) || (gy.stats && ((gy.ystride & 3) || ((uintptr_t)gy.y & 15)))) return -2;
     if (fuse.bsums && ((fuse.x.sstride & 3) || ((uintptr_t)fuse.x.data & 15))) return -2;
@@ -681,7 +690,7 @@ int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, 
 int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
 {
     static const int on = [] { const char* e = getenv("MFVI_RP"); return !(e && e[0] == '0'); }();
-    if (!on || g.ks != 3 || g.stride != 1 || ((g.W & 63) && !(g.W == 32 && mode == 0 && (g.H & 7) == 0)) || (g.H & 3)) return 0;
+    if (!on || g.ks != 3 || g.stride != 1 || ((g.W & 63) && !(g.W == 32 && (g.H & 7) == 0)) || (g.H & 3)) return 0;
     static const int forced = [] { int mf = 0, r = 0, T = 1, rem = 0, ks = 1; const char* e = getenv("MFVI_TUNE_RP"); if (e) sscanf(e, "%d,%d,%d,%d,%d", &mf, &r, &T, &rem, &ks); return mf > 0 ? (mf | r << 8 | (rem & 1) << 12 | (ks & 7) << 13 | T << 16) : 0; }();
     if (forced) return forced | MFVI_TUNE_RP;
     const int MOUT = mode == 0 ? g.Cout : g.Cin;
@@ -690,7 +699,7 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
     if (mo < 16) return 0;
     if (mode == 1 && g.Cout < 16) return 0;
     const int mf = (mo % 32 == 0) ? 2 : 1;
-    const long long units = (long long)(g.W / 64) * (g.H / 4) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles, one per block
+    const long long units = (long long)max(1, g.W / 64) * (g.H / (g.W == 32 ? 8 : 4)) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles, one per block
     // measured on the three big layers (profiles/r03_rp_layers.txt): forward — tall tiles (fewer stage barriers per MFMA) while the grid
     // still fills the chip twice; backward-data — 4-row tiles (the out tile of the fold is LDS) and several tiles per block (the last
     // tile's fold and the block prologue are exposed once per block)

@@ -160,3 +160,42 @@ def test_rowphase_forward_on_32_wide_maps(M, case):
     assert relerr(got[0], ref[0]) < 1e-6
     for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
         assert relerr(a, b) < 2e-5, name
+
+
+@pytest.mark.parametrize("shape", [(36, 16, 8, 32), (36, 16, 16, 32), (68, 32, 32, 32), (20, 16, 24, 32), (132, 64, 16, 32), (16, 48, 48, 32)])
+def test_rowphase_backward_data_on_32_wide_maps(M, shape):
+    """Fused-fold backward-data on maps 32 wide (W32): image rows 1 and H-2 (the reflection adjoint's spare window rows) live in the upper
+    half of the first tile and the lower half of the last one, both halves carry both border columns; one tile that is first AND last
+    (H = 8 with 4-row halves, H = 16 with 8-row halves), several tiles per block, 4-channel remainder.  Against the round-2 tiling."""
+    cin, cout, H, W = shape
+    n, seed = 2, 89
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, enc(1, 8, 1))); M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    tried = 0
+    for mf, r, T, rem in [(1, 1, 1, 0), (1, 2, 1, 0), (2, 1, 1, 0), (1, 1, 2, 0), (1, 1, 3, 0), (1, 1, 1, 1), (1, 2, 1, 1), (2, 1, 2, 1)]:
+        if H % (8 * r):
+            continue
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc_rp(mf, r, T, rem)))
+        try:
+            got = _run_plan(plan, P, seed, n, z, dout)
+        except M._lib.MfviError:
+            continue
+        finally:
+            fam = lib.mfvi_plan_last_kernel(plan.handle, 1, 1)
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
+        if fam != 2:
+            continue
+        tried += 1
+        assert relerr(got[0], ref[0]) < 1e-6, ("out", mf, r, T, rem)
+        for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+            assert relerr(a, b) < 2e-5, (name, mf, r, T, rem)
+    assert tried >= 2, tried
+
+
+def test_rowphase_small_net_32_wide_against_oracle(M):
+    """Hour-glass net whose top scale is 32 wide: default dispatch (row-phase forward and backward-data, W32) against the oracle."""
+    test_rowphase_small_nets_against_oracle(M, dict(H=32, W=32, input_depth=8, n_out=2, nd=(16, 32), nu=(16, 32), ns=(4, 4)))
