@@ -367,6 +367,29 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax)
         return dt
+    # N > 1: the exchange after the backward pass, or started under its tail (ElboEngine.set_allreduce_overlap)?  Both schedules give the
+    # same update; which one is faster depends on the node's links, so it is timed here (untimed by the contract) like a kernel tiling.
+    overlap = None
+    if world > 1 and args.mode == "engine":
+        mode = os.environ.get("MFVI_AR_OVERLAP", "auto")
+        if mode == "auto":
+            ab = {}
+            for ov in (False, True, False, True):
+                eng.set_allreduce_overlap(ov)
+                for _ in range(3):
+                    eng.step()
+                ab[ov] = min(ab.get(ov, 1e9), timed(eng, 10) / 10)      # (max over ranks: every rank takes the same decision)
+            use = ab[True] < ab[False]
+            overlap = {"used": bool(use), "chosen": "timed", "ms_per_step_after_backward": 1e3 * ab[False], "ms_per_step_overlapped": 1e3 * ab[True]}
+        else:
+            use = mode == "1"
+            overlap = {"used": bool(use), "chosen": "MFVI_AR_OVERLAP=" + mode}
+        eng.set_allreduce_overlap(use)
+        if use:
+            overlap["split"] = {"first_op": eng._ov["op"], "tail_floats": 2 * (eng.n_vi - eng._ov["off"]), "head_floats": int(eng._ov["head"].numel())}
+        eng._ar_events = []
+        for _ in range(2):
+            eng.step()
     eng.plan.profile(2, dom_op, dom_pass)
     dt = timed(eng, args.steps)
     recs = eng.plan.profile_read()
@@ -377,6 +400,7 @@ def main():
     strong_extra = None
     if world > 1 and not strong and k_strong % world == 0:
         eng2 = make_engine(cfg, k_strong, rank, world, torch)
+        eng2.set_allreduce_overlap(bool(overlap and overlap["used"]))
         for _ in range(max(args.warmup, 6)):      # a collective's first calls on a new buffer set up staging / channels (gloo: ~0.25 s once)
             eng2.step()
         dt2 = timed(eng2, args.steps)
@@ -458,7 +482,8 @@ def main():
         if strong_extra:
             res["strong_scaling"] = strong_extra
         if world > 1:
-            res["allreduce_ms"] = eng.allreduce_ms()        # mean duration of the gradient all-reduce (HIP events around the collective)
+            res["allreduce_ms"] = eng.allreduce_ms()        # mean time of the exchange on the caller's stream (HIP events); overlapped: what is left exposed
+            res["allreduce_overlap"] = overlap
         if cfg["task"] == "den" and S == 256:
             res["reference_cpu_probe"] = REFERENCE_CPU_PROBE
         if args.mode == "dropin":

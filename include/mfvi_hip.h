@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define MFVI_ABI_VERSION 4
+#define MFVI_ABI_VERSION 5
 
 typedef struct mfvi_plan mfvi_plan;
 
@@ -110,6 +110,17 @@ void mfvi_plan_destroy(mfvi_plan* plan);
  * mfvi_forward uses it too: a skip-branch convolution on a small map (<= MFVI_FWD_FORK pixels, default 128 x 128; 0 = never) runs there
  * beside the down path of its scale and is joined in front of its concat. */
 int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled);
+/* Gradient split for an overlapped exchange (K sharded over ranks: DESIGN.md section 7; the reference has one process per fit and no exchange,
+ * bayesian_optimization.py:3760-3775).  The flat layout is in op order and the backward pass runs the ops last to first, so the weight /
+ * bias gradients of the ops >= first_op — the tail [offset, n_vi) of dmu and of drho — are complete long before the pass ends.  With a
+ * split set, mfvi_backward reduces that group into dmu / drho on comm_stream as soon as the kernels producing it are enqueued (comm_stream
+ * waits for them through events), and the rest at the end on the caller's stream as before: a collective enqueued on comm_stream after
+ * mfvi_backward returns runs under the tail of the pass.  The caller joins comm_stream before it reads the gradients and before the
+ * next mfvi_backward.  Results are bit-identical with and without a split.  first_op < 0 removes the split.  Not available for plans with
+ * local-reparameterisation layers (their d rho is completed in one pass at the end).  mfvi_plan_grad_split_offset returns the tail's
+ * first parameter index (-1 and an error if the ops >= first_op do not own a tail of the layout). */
+int mfvi_plan_set_grad_split(mfvi_plan* plan, int first_op, void* comm_stream);
+int mfvi_plan_grad_split_offset(const mfvi_plan* plan, int first_op, int64_t* offset);
 /* Dropout2d layers of the program are active by default (the reference keeps its MC-dropout nets in train mode);
  * enabled = 0 makes them the identity (nn.Dropout2d in eval mode). */
 int mfvi_plan_set_dropout(mfvi_plan* plan, int enabled);

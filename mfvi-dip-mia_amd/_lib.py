@@ -38,6 +38,8 @@ SIGNATURES = {
     "mfvi_plan_bn_update_running": (_I, [_P, _P, _I, _F, _P, _P]),
     "mfvi_plan_set_bn_eval": (_I, [_P, _P]),
     "mfvi_plan_set_side_stream": (_I, [_P, _I]),
+    "mfvi_plan_set_grad_split": (_I, [_P, _I, _P]),
+    "mfvi_plan_grad_split_offset": (_I, [_P, _I, _P]),
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
     "mfvi_backward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mfvi_plan_read_tensor": (_I, [_P, _P, _I, _I, _I, _P, _P]),

@@ -80,6 +80,11 @@ struct mfvi_plan {
     std::vector<hipEvent_t> fwd_events;        // forward pass: skip-branch convolutions beside the down path (MFVI_FWD_FORK)
     GradFinEntry* fin_dev = nullptr;           // table of the layers whose partial dW slabs grad_finalize reduces
     std::vector<GradFinEntry> fin_uploaded;
+    // Gradient split for an overlapped exchange (mfvi_plan_set_grad_split): the backward pass reduces the weight gradients of the ops
+    // >= split_op on split_stream as soon as their backward-weight kernels have been enqueued, the rest at the end as before.  The early
+    // group has its own half of the device table (fin_dev + n_conv).
+    int split_op = -1; hipStream_t split_stream = nullptr; hipEvent_t split_ev[2] = {nullptr, nullptr}; int n_conv = 0;
+    std::vector<GradFinEntry> fin_uploaded_early;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
     struct Rec { int op, pass; hipEvent_t a, b; };
     int prof_mode = 0, prof_op = -1, prof_pass = -1;      // 0 off, 1 every kernel, 2 only (prof_op, prof_pass)
@@ -259,7 +264,8 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
         }
     p.total_bytes = p.float_base + fo * (long long)sizeof(float);
     if (n_conv) {
-        const hipError_t e = hipMalloc((void**)&p.fin_dev, sizeof(GradFinEntry) * n_conv);
+        p.n_conv = n_conv;
+        const hipError_t e = hipMalloc((void**)&p.fin_dev, sizeof(GradFinEntry) * n_conv * 2);      // second half: the early group of a gradient split
         if (e != hipSuccess) return fail("plan: hipMalloc of the gradient table failed: %s", hipGetErrorString(e));
     }
     p.n_entries = (int)table.size();
@@ -424,6 +430,7 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     for (auto e : plan->fork_events) (void)hipEventDestroy(e);
     for (auto e : plan->fwd_events) (void)hipEventDestroy(e);
     if (plan->join_event) (void)hipEventDestroy(plan->join_event);
+    for (auto e : plan->split_ev) if (e) (void)hipEventDestroy(e);
     if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
@@ -434,6 +441,36 @@ int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled)
 {
     if (!plan) { set_error("set_side_stream: null plan"); return -1; }
     plan->side_enabled = enabled != 0;
+    return 0;
+}
+
+int mfvi_plan_grad_split_offset(const mfvi_plan* plan, int first_op, int64_t* offset)
+{
+    if (!plan || !offset || first_op < 0 || first_op >= (int)plan->ops.size()) { set_error("grad_split_offset: bad arguments"); return -1; }
+    if (plan->n_lrt) { set_error("grad_split_offset: plans with local-reparameterisation layers reduce d rho in one pass at the end"); return -1; }
+    long long lo = plan->n_vi, head_end = 0;
+    for (int i = 0; i < (int)plan->ops.size(); ++i) {
+        const OpInfo& o = plan->ops[i];
+        if (o.d.type != MFVI_OP_CONV) continue;
+        const long long nw = (long long)o.g.Cout * o.g.Cin * o.g.ks * o.g.ks;
+        const long long a = o.g.b_off >= 0 ? std::min<long long>(o.g.w_off, o.g.b_off) : o.g.w_off;
+        const long long b = std::max<long long>(o.g.w_off + nw, o.g.b_off >= 0 ? o.g.b_off + o.g.Cout : 0);
+        if (i >= first_op) lo = std::min(lo, a); else head_end = std::max(head_end, b);
+    }
+    if (head_end > lo) { set_error("grad_split_offset: the parameters of the ops >= %d are not a tail of the flat layout", first_op); return -1; }
+    *offset = lo;
+    return 0;
+}
+
+int mfvi_plan_set_grad_split(mfvi_plan* plan, int first_op, void* comm_stream)
+{
+    if (!plan) { set_error("set_grad_split: null plan"); return -1; }
+    if (first_op < 0) { plan->split_op = -1; plan->split_stream = nullptr; return 0; }
+    int64_t off = 0;
+    if (mfvi_plan_grad_split_offset(plan, first_op, &off)) return -1;
+    for (auto& e : plan->split_ev)
+        if (!e) { const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (rc != hipSuccess) { set_error("set_grad_split: event creation failed: %s", hipGetErrorString(rc)); return (int)rc; } }
+    plan->split_op = first_op; plan->split_stream = (hipStream_t)comm_stream;
     return 0;
 }
 
@@ -731,6 +768,28 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     auto settle = [&]() {                     // after that launch: consumed (the event is on the kernel's packet) or not
         if (mfvi_tl_stop_event) { mfvi_tl_stop_event = nullptr; armed_idx = -1; }
     };
+    // reduction of the partial dW slabs of the layers collected in `fin` into dmu / drho, on stream fs from the device table tab
+    auto finalize = [&](hipStream_t fs, GradFinEntry* tab, std::vector<GradFinEntry>& uploaded) -> int {
+        if (fin.empty()) return 0;
+        // longest blocks first: a block's work grows with the number of pixel strips of its layer
+        std::stable_sort(fin.begin(), fin.end(), [](const GradFinEntry& a, const GradFinEntry& b) { return a.strips > b.strips; });
+        fin_blocks = 0;
+        for (auto& e : fin) { e.first_block = fin_blocks; fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS; }
+        ProfScope ps(plan, -1, PASS_GRAD_FINALIZE, fs);
+        const bool same = fin.size() == uploaded.size() && memcmp(fin.data(), uploaded.data(), sizeof(GradFinEntry) * fin.size()) == 0;
+        if (!same) {      // tilings change only when the plan is (re)tuned: the table is uploaded once in steady state
+            if (getenv("MFVI_DEBUG_FIN")) for (auto& e : fin) fprintf(stderr, "fin layer %d n_w %d strips %d first_block %d\n", e.layer_id, e.n_w, e.strips, e.first_block);
+            uploaded = fin;      // (the copy reads the plan-owned vector: `fin` is reused by the caller)
+            const hipError_t e = hipMemcpyAsync(tab, uploaded.data(), sizeof(GradFinEntry) * uploaded.size(), hipMemcpyHostToDevice, fs);
+            if (e != hipSuccess) { uploaded.clear(); set_error("backward: gradient table upload failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        // every layer of `fin` (MFMA backward-weight) is also in the sampling table (same shape conditions), so its W_k sit in the slab
+        const int rc = launch_grad_finalize(tab, (int)fin.size(), fin_blocks, c.farena(), rho_v, key, sample_weights, n_samples, dmu, drho,
+                                            presample && sample_weights && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu_v, fs, bf16);
+        if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+        fin.clear(); fin_blocks = 0;
+        return 0;
+    };
     // the join event rides on the side stream's last launch (the backward-weight kernel of the last op that forks)
     int last_fork_op = -1;
     for (int j = 0; j < (int)plan->ops.size(); ++j) if (will_fork(j)) { last_fork_op = j; break; }
@@ -863,30 +922,23 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
             if (side != st) (void)hipStreamSynchronize(side);   // leave no side-stream work behind a failed call
             return rc;
         }
+        if (i == plan->split_op && plan->split_stream && plan->split_stream != st) {
+            // gradient split: every kernel that writes a weight gradient of the ops >= i (partial slabs on the side stream, generic
+            // kernels' atomics on either stream) has been enqueued; the exchange stream waits for them and reduces that group now
+            hipError_t e = hipEventRecord(plan->split_ev[0], st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(plan->split_stream, plan->split_ev[0], 0);
+            if (e == hipSuccess && side != st) { e = hipEventRecord(plan->split_ev[1], side); if (e == hipSuccess) e = hipStreamWaitEvent(plan->split_stream, plan->split_ev[1], 0); }
+            if (e != hipSuccess) { set_error("backward: gradient split failed: %s", hipGetErrorString(e)); if (side != st) (void)hipStreamSynchronize(side); return (int)e; }
+            const int r2 = finalize(plan->split_stream, plan->fin_dev + plan->n_conv, plan->fin_uploaded_early);
+            if (r2) { if (side != st) (void)hipStreamSynchronize(side); return r2; }
+        }
     }
     if (side != st) {        // join: grad_finalize (and the caller) see every partial slab / accumulated gradient
         hipError_t e = join_on_packet ? hipSuccess : hipEventRecord(plan->join_event, side);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, plan->join_event, 0);
         if (e != hipSuccess) { set_error("backward: join failed: %s", hipGetErrorString(e)); return (int)e; }
     }
-    if (!fin.empty()) {
-        // longest blocks first: a block's work grows with the number of pixel strips of its layer
-        std::stable_sort(fin.begin(), fin.end(), [](const GradFinEntry& a, const GradFinEntry& b) { return a.strips > b.strips; });
-        fin_blocks = 0;
-        for (auto& e : fin) { e.first_block = fin_blocks; fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS; }
-        ProfScope ps(plan, -1, PASS_GRAD_FINALIZE, st);
-        const bool same = fin.size() == plan->fin_uploaded.size() && memcmp(fin.data(), plan->fin_uploaded.data(), sizeof(GradFinEntry) * fin.size()) == 0;
-        if (!same) {      // tilings change only when the plan is (re)tuned: the table is uploaded once in steady state
-            if (getenv("MFVI_DEBUG_FIN")) for (auto& e : fin) fprintf(stderr, "fin layer %d n_w %d strips %d first_block %d\n", e.layer_id, e.n_w, e.strips, e.first_block);
-            const hipError_t e = hipMemcpyAsync(plan->fin_dev, fin.data(), sizeof(GradFinEntry) * fin.size(), hipMemcpyHostToDevice, st);
-            if (e != hipSuccess) { set_error("backward: gradient table upload failed: %s", hipGetErrorString(e)); return (int)e; }
-            plan->fin_uploaded = fin;
-        }
-        // every layer of `fin` (MFMA backward-weight) is also in the sampling table (same shape conditions), so its W_k sit in the slab
-        const int rc = launch_grad_finalize(plan->fin_dev, (int)fin.size(), fin_blocks, c.farena(), rho_v, key, sample_weights, n_samples, dmu, drho,
-                                            presample && sample_weights && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu_v, st, bf16);
-        if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
-    }
+    { const int rc = finalize(st, plan->fin_dev, plan->fin_uploaded); if (rc) return rc; }
     if (plan->n_lrt && sample_weights) {      // d rho += d sigma^2 * 2 softplus(rho) sigmoid(rho)
         const int rc = launch_lrt_drho(c.farena() + plan->dsig2_off, rho, plan->n_vi, drho, st);
         if (rc) { set_error("backward: lrt_drho launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }

@@ -150,6 +150,7 @@ class ElboEngine:
         lib, sp = L.lib(), L.stream_ptr()
         step = self.t if step is None else step
         self._gbuf.zero_()                     # grads and acc
+        exchange = self.world > 1 or getattr(self, "_force_exchange", False)
         zsrc = self.z0
         if perturb:
             L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
@@ -160,20 +161,25 @@ class ElboEngine:
             self._loss_and_dout(n)
             if after_forward is not None and c0 + n >= self.K_local:
                 after_forward(n)       # self.out holds the n samples of the LAST launch, final in stream order here: work that only reads it can overlap the backward pass
-            self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn,
-                               self.sample_weights)
-        if self.world > 1:
-            # the single exchange of the K-sharded step: grads (+ the NLL scalar) summed over ranks
-            self.grads[self.n_params] = self.acc[0].float()
-            if self.grads.is_cuda:      # HIP events around the collective (bench.py's allreduce_ms): recorded on the stream it is enqueued on
+            split = exchange and getattr(self, "_ov", None) is not None and c0 + n >= self.K_local      # the gradients are final after the LAST launch
+            if split:
+                self.plan.grad_split(self._ov["op"], self._ov["stream"])
+            try:
+                self.plan.backward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.dout, self.dmu, self.drho, self.dbn,
+                                   self.sample_weights)
+            finally:
+                if split:
+                    self.plan.grad_split(-1)
+        if exchange:
+            if self.grads.is_cuda:      # HIP events around the exchange (bench.py's allreduce_ms): on the caller's stream — with the overlap on, what is left exposed
                 ev = self._ar_events = getattr(self, "_ar_events", [])
                 if len(ev) >= 64:
                     ev.pop(0)
                 a_, b_ = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
-                a_.record(); allreduce_sum_(self.grads, self.pg); b_.record()
+                a_.record(); self._exchange(); b_.record()
                 ev.append((a_, b_))
             else:
-                allreduce_sum_(self.grads, self.pg)
+                self._exchange()
         if with_kl:
             # KL and its gradient are deterministic: every rank computes them redundantly (no communication)
             mu, rho = self.mu, self.rho
@@ -182,6 +188,40 @@ class ElboEngine:
             L.check(lib.mfvi_kl(L.ptr(mu), L.ptr(rho), self.n_vi, 0.0, self.prior_sigma, L.ptr(self.acc[1:]), sp))
             L.check(lib.mfvi_kl_backward(L.ptr(mu), L.ptr(rho), self.n_vi, 0.0, self.prior_sigma, self.temp,
                                          L.ptr(self.dmu), L.ptr(self.drho), sp))
+
+    def set_allreduce_overlap(self, enabled, tail_fraction=0.9):
+        """K sharded over ranks: start the exchange under the tail of the backward pass.  The weight gradients of the deep / up-path ops —
+        a tail of the flat layout holding >= tail_fraction of the parameters — are complete when the backward pass (last op first) reaches
+        the top scales of the down path; the plan reduces them on a second stream there (mfvi_plan_set_grad_split) and their all-reduce is
+        enqueued on that stream, beside the rest of the pass.  The head of the layout, d BN and the NLL scalar follow in one packed
+        all-reduce after the pass.  Same sums in the same order either way: the update is bit-identical (tests/test_gpu_multirank.py)."""
+        self._ov = None
+        if not enabled:
+            return
+        op, off = self.plan.choose_grad_split(tail_fraction)
+        n_rest = self.grads.numel() - 2 * self.n_vi               # d BN + the 8 scalars
+        self._ov = dict(op=op, off=off, stream=self.torch.cuda.Stream(),
+                        head=self.torch.empty(2 * off + n_rest, dtype=self.torch.float32, device=self.grads.device))
+
+    def _exchange(self):
+        """The single exchange of the K-sharded step: grads (+ the NLL scalar) summed over ranks."""
+        torch, ov, n_vi = self.torch, getattr(self, "_ov", None), self.n_vi
+        self.grads[self.n_params] = self.acc[0].float()
+        force = getattr(self, "_force_exchange", False)
+        if ov is None:
+            allreduce_sum_(self.grads, self.pg, force)
+            return
+        off, head, main = ov["off"], ov["head"], torch.cuda.current_stream()
+        with torch.cuda.stream(ov["stream"]):       # behind the plan's early gradient reduction (stream order), beside the rest of the pass
+            allreduce_sum_(self.dmu[off:], self.pg, force)
+            allreduce_sum_(self.drho[off:], self.pg, force)
+        pieces = (self.dmu[:off], self.drho[:off], self.grads[2 * n_vi:])
+        torch.cat(pieces, out=head)
+        allreduce_sum_(head, self.pg, force)
+        o = 0
+        for p in pieces:
+            p.copy_(head[o:o + p.numel()]); o += p.numel()
+        main.wait_stream(ov["stream"])
 
     def allreduce_ms(self):
         """Mean duration (ms) of the gradient all-reduce over the last <= 64 iterations, from events on the stream it was enqueued on

@@ -171,6 +171,30 @@ class Plan:
         """Backward-weight kernels on the plan's side stream (default) or on the caller's stream."""
         L.check(L.lib().mfvi_plan_set_side_stream(self.handle, int(bool(enabled))))
 
+    def grad_split(self, first_op, stream=None):
+        """mfvi_plan_set_grad_split: the weight gradients of the ops >= first_op are reduced on `stream` (a torch.cuda.Stream) as soon as
+        the backward pass has enqueued their kernels; first_op < 0 removes the split."""
+        L.check(L.lib().mfvi_plan_set_grad_split(self.handle, int(first_op), None if first_op < 0 else C.c_void_p(stream.cuda_stream)))
+
+    def grad_split_offset(self, first_op):
+        """First parameter index of the flat-layout tail owned by the ops >= first_op."""
+        off = C.c_int64(0)
+        L.check(L.lib().mfvi_plan_grad_split_offset(self.handle, int(first_op), C.byref(off)))
+        return off.value
+
+    def choose_grad_split(self, tail_fraction=0.9):
+        """-> (first_op, offset): the LAST op (the earliest point of the backward pass, which runs the ops last to first) whose tail of
+        the flat layout still holds at least tail_fraction of the variational parameters."""
+        best = None
+        for i, o in enumerate(self.prog.ops):
+            if o["type"] != L.OP_CONV:
+                continue
+            if self.prog.n_vi - o["w_off"] >= tail_fraction * self.prog.n_vi:
+                best = i
+        if best is None:
+            raise ValueError("no op owns a tail of %.2f of the parameters" % tail_fraction)
+        return best, self.grad_split_offset(best)
+
     def profile(self, mode, op=-1, pass_=-1):
         L.check(L.lib().mfvi_plan_profile(self.handle, mode, op, pass_))
 

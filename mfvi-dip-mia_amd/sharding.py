@@ -14,9 +14,10 @@ def shard_samples(K, rank, world_size):
     return rank * k_local, k_local
 
 
-def allreduce_sum_(flat, group=None):
-    """In-place sum over ranks of the flat [d mu | d rho | d BN | scalars] buffer."""
+def allreduce_sum_(flat, group=None, force=False):
+    """In-place sum over ranks of the flat [d mu | d rho | d BN | scalars] buffer (or of a slice of it: engine.set_allreduce_overlap).
+    force: issue the collective on a one-rank group too (tests of the stream schedule on a one-GPU box)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
