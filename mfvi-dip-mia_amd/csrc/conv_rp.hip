@@ -64,13 +64,16 @@ __device__ __forceinline__ unsigned long long rp_now() { unsigned long long t; a
 // (chan_bwd's  c1 * (ga - c2 - xhat * c3)  with the products of the channel constants formed once per block)
 struct RpBwd { float mean, qc, c1, k2; };
 
-// W32 (maps exactly 32 wide): the 64 "pixels" of a strip are TWO image rows side by side — lanes n = 0..7 the quads of image
-// row y, lanes 8..15 those of image row y + TH (the tile is 2 TH image rows tall) — so the vertical taps are +-1 window row for both
-// halves; a window row is [34 columns of the upper half + 2 pad | 34 columns of the lower half + 2 pad] = 18 quads, and a lane's six floats
-// start at 4 (n + (n >> 3)).  Both halves carry both image borders.
-template <int R, int MODE, bool W32 = false>
+// Narrow maps (WSH > 0: maps exactly 32 or 16 wide = 2^WSH float4 columns, WSH = 3 / 2): the 64 "pixels" of a strip are NSUB = 2 / 4 image rows
+// side by side — lanes n = 0..7 the quads of image row y, lanes 8..15 those of image row y + TH (32 wide; 16 wide: four groups of four
+// lanes, TH rows apart; the tile is NSUB * TH image rows tall) — so the vertical taps are +-1 window row for every group; a window row is
+// NSUB x [W + 2 columns + 2 pad] = 18 / 20 quads, and a lane's six floats start at 4 (n + (n >> WSH)).  Every group carries both image borders.
+template <int R, int MODE, int WSH = 0>
 struct RpCfg {
-    static constexpr int TH = 4 * R, WROWS = TH + 2, NQ = W32 ? 18 : 17, PITCH = 4 * NQ;       // 66 window columns -> 17 quads
+    static constexpr bool W32 = WSH > 0;                    // (name kept from the first, 32-wide version: "narrow map")
+    static constexpr int QPR = WSH > 0 ? (1 << WSH) : 16;   // float4 columns per image row inside the strip
+    static constexpr int NSUB = 16 / QPR;                   // image rows side by side
+    static constexpr int TH = 4 * R, WROWS = TH + 2, NQ = WSH > 0 ? NSUB * (QPR + 1) : 17, PITCH = 4 * NQ;       // 66 window columns -> 17 quads
     // MODE 1: two extra rows per channel plane hold the row part of the reflection adjoint (S1 = dy[2] + dy[0] for image row 1,
     // S2 = dy[H-3] + dy[H-1] for image row H-2; see the kernel's header)
     static constexpr int PROWS = WROWS + (MODE == 1 ? 2 : 0);
@@ -80,12 +83,13 @@ struct RpCfg {
 
 // MINW: minimum waves per SIMD the register allocation must allow (4 = 128 VGPRs = two 512-thread blocks per CU)
 // KS: 4-channel k-steps per stage (one barrier per stage: a stage boundary costs ~800 cycles of matrix time, see NOTES)
-template <int MODE, int MF, int R, bool REM, int KS, int MINW, bool W32 = false>
+template <int MODE, int MF, int R, bool REM, int KS, int MINW, int WSH = 0>
 __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
 {
     static_assert(!REM || MODE == 1, "remainder channels: backward-data only");
     static_assert(MODE == 0 || R <= 2, "backward-data: image rows 1 / H-2 must be the last / first row of their wave");
-    using Cfg = RpCfg<R, MODE, W32>;
+    using Cfg = RpCfg<R, MODE, WSH>;
+    constexpr bool W32 = WSH > 0; constexpr int QPR = Cfg::QPR, NSUB = Cfg::NSUB;
     constexpr int TH = Cfg::TH, PITCH = Cfg::PITCH, PLANE = Cfg::PLANE, NITEM = Cfg::NITEM, NV = Cfg::NV;
     constexpr int CT = 16 * MF, CTX = CT + (REM ? 4 : 0);
     constexpr int WFR = 4 * 16 * 12;                           // floats of one output fragment's weight chunk: [k 4][m 16][ky 3][4]
@@ -166,14 +170,14 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         bool sp1 = false, sp2 = false;      // MODE 1: the tile of the stage in registers holds image row 1 / H-2
         float4 xv[KS][NV], yv[MODE == 1 ? KS : 1][MODE == 1 ? NV : 1];
         auto set_tile = [&](int tile) {
-            const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
+            const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * NSUB * TH : (tile / A.tiles_x) * TH;
             flags = 0; anyf = 0;
-            sp1 = MODE == 1 && py0 == 0; sp2 = MODE == 1 && py0 + (W32 ? 2 : 1) * TH == H;      // (W32: image row H - 2 sits in the lower half of the last tile)
+            sp1 = MODE == 1 && py0 == 0; sp2 = MODE == 1 && py0 + (W32 ? NSUB : 1) * TH == H;      // (narrow maps: image row H - 2 sits in the last group of the last tile)
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int q = min(lane + 64 * j, NITEM - 1), iy = q / Cfg::NQ, v = q - iy * Cfg::NQ;
                 int gy = py0 - 1 + iy, gx = px0 - 1 + 4 * v; unsigned flag = 0;
-                if (W32) { const int sub = v >= 9 ? 1 : 0; gy += sub * TH; gx = -1 + 4 * (v - 9 * sub); }      // lower half: image rows TH further down
+                if (W32) { const int sub = v / (QPR + 1); gy += sub * TH; gx = -1 + 4 * (v - (QPR + 1) * sub); }      // group sub: image rows sub * TH further down
                 if (MODE == 0) { gy = reflect_idx(gy, H); gy = min(max(gy, 0), H - 1); }
                 else if (gy < 0 || gy >= H) { flag = 3; gy = 0; }
                 if (gx < 0) { if (flag == 0) flag = 1; gx = 0; }
@@ -320,13 +324,13 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             constexpr int part = decltype(part_c)::value;
             if constexpr (MODE == 1) {
                 if (!fuse_sums) return;
-                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
+                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * NSUB * TH : (tile / A.tiles_x) * TH;
                 const float* __restrict__ xq = A.xin.data + (long long)k * A.xin.sstride + (long long)m0 * HW + py0 * W + px0;
                 int tl = t; asm volatile("" : "+v"(tl));       // the items' index arithmetic is recomputed here, not hoisted over the stage loop (27 registers)
 #pragma unroll
                 for (int j = part; j < NIT; j += FP) {
                     const int idx = tl + 256 * j, ch = idx / (TH * 16), rw = (idx >> 4) % TH, v = idx & 15;
-                    const int po = W32 ? (rw + (v >> 3) * TH) * W + 4 * (v & 7) : rw * W + 4 * v;      // (W32: float4 column v >= 8 = the lower half)
+                    const int po = W32 ? (rw + (v >> WSH) * TH) * W + 4 * (v & (QPR - 1)) : rw * W + 4 * v;      // (narrow maps: float4 column v = group v >> WSH)
                     fxr[j / FP] = ch < mtx ? *reinterpret_cast<const float4*>(xq + ch * HW + po) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         auto fold_do = [&](int tile, auto part_c) {
             constexpr int part = decltype(part_c)::value;
             if constexpr (MODE == 1) {
-                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
+                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * NSUB * TH : (tile / A.tiles_x) * TH;
                 float* __restrict__ o = A.fga + (long long)k * A.fga_sstride + (long long)m0 * HW + py0 * W + px0;
                 const int xact = A.xin.act; const float xslope = A.xin.slope;
                 int tl = t; asm volatile("" : "+v"(tl));
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                                 for (int l = 0; l < 4; ++l) { fsum[j] += dd[l]; fxs[j] = __builtin_fmaf(dd[l], yy[l] - cf.mean, fxs[j]); }
                             }
                         }
-                        *reinterpret_cast<float4*>(o + ch * HW + (W32 ? (rw + (v >> 3) * TH) * W + 4 * (v & 7) : rw * W + 4 * v)) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+                        *reinterpret_cast<float4*>(o + ch * HW + (W32 ? (rw + (v >> WSH) * TH) * W + 4 * (v & (QPR - 1)) : rw * W + 4 * v)) = make_float4(dd[0], dd[1], dd[2], dd[3]);
                     }
                 }
             }
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
         // ======================= consumer waves =======================
         const bool do_stats = MODE == 0 && A.out.stats != nullptr;
         if (do_stats) for (int q = lane; q < CTX; q += 64) { s_red[wv][q][0] = 0.0; s_red[wv][q][1] = 0.0; }
-        const int xb = l4 * PLANE + (wv * R) * PITCH + 4 * (l15 + (W32 ? l15 >> 3 : 0));      // this lane's six-float window read, row 0 of the wave
+        const int xb = l4 * PLANE + (wv * R) * PITCH + 4 * (l15 + (W32 ? l15 >> WSH : 0));      // this lane's six-float window read, row 0 of the wave
         const int wb = (l4 * 16 + l15) * 12;                             // weights of (k = l4, m = l15)
         const int wxb = MF * WFR + (l4 * 4 + (lane & 3)) * 12;           // REM: A operand of the 4x4x1 instruction = w[extra channel lane & 3][k = l4]
         __syncthreads();                                  // (S0)
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
             for (int it = 0; it < n_iters; ++it) {
                 RP_T(c0);
                 const int tile = TILE(it / n_chunks), ci = it % n_chunks;
-                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * 2 * TH : (tile / A.tiles_x) * TH;
+                const int px0 = W32 ? 0 : (tile % A.tiles_x) * 64, py0 = W32 ? tile * NSUB * TH : (tile / A.tiles_x) * TH;
                 const int row0 = py0 + wv * R;                               // first image row of this wave
                 if (ci == 0) {
     #pragma unroll
@@ -472,10 +476,10 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
     #pragma unroll
                 for (int rr = 0; rr < R + 2; ++rr) {
                     int ro = rr * PITCH;
-                    if constexpr (MODE == 1) {          // the spare window rows S1 / S2 stand in for dy[2] / dy[H-3] (header): wave-uniform; W32: for the lanes of ONE half
+                    if constexpr (MODE == 1) {          // the spare window rows S1 / S2 stand in for dy[2] / dy[H-3] (header): wave-uniform; narrow maps: for the lanes of the first / last group
                         if constexpr (W32) {
-                            if (rr == R + 1 && row0 + R - 1 == 1 && l15 < 8) ro = (Cfg::WROWS - wv * R) * PITCH;
-                            if (rr == 0 && row0 + TH == H - 2 && l15 >= 8) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
+                            if (rr == R + 1 && row0 + R - 1 == 1 && l15 < QPR) ro = (Cfg::WROWS - wv * R) * PITCH;
+                            if (rr == 0 && row0 + (NSUB - 1) * TH == H - 2 && l15 >= 16 - QPR) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
                         } else {
                             if (rr == R + 1 && row0 + R - 1 == 1) ro = (Cfg::WROWS - wv * R) * PITCH;
                             if (rr == 0 && row0 == H - 2) ro = (Cfg::WROWS + 1 - wv * R) * PITCH;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                 if constexpr (MODE == 1) {
                     // column part of the reflection adjoint: image column 1 (phase 1 of lane 0 in the leftmost tile) takes tap kx = 2 from
                     // win[3] + win[1]; column W-2 (phase 2 of lane 15 in the rightmost tile) takes tap kx = 0 from win[2] + win[4]
-                    const float ml = (W32 ? (l15 & 7) == 0 : (px0 == 0 && l15 == 0)) ? 1.f : 0.f, mr = (W32 ? (l15 & 7) == 7 : (px0 + 64 == W && l15 == 15)) ? 1.f : 0.f;
+                    const float ml = (W32 ? (l15 & (QPR - 1)) == 0 : (px0 == 0 && l15 == 0)) ? 1.f : 0.f, mr = (W32 ? (l15 & (QPR - 1)) == QPR - 1 : (px0 + 64 == W && l15 == 15)) ? 1.f : 0.f;
     #pragma unroll
                     for (int rr = 0; rr < R + 2; ++rr) { b[rr][6] = __builtin_fmaf(ml, b[rr][1], b[rr][3]); b[rr][7] = __builtin_fmaf(mr, b[rr][4], b[rr][2]); }
                 }
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
                                     const float bi = s_bias[ml];
                                     const float v0 = acc[f][r][0][q] + bi, v1 = acc[f][r][1][q] + bi, v2 = acc[f][r][2][q] + bi, v3 = acc[f][r][3][q] + bi;
                                     if (ml < mt) {
-                                        if constexpr (W32) *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r + (l15 >> 3) * TH) * W + 4 * (l15 & 7)) = make_float4(v0, v1, v2, v3);
+                                        if constexpr (W32) *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r + (l15 >> WSH) * TH) * W + 4 * (l15 & (QPR - 1))) = make_float4(v0, v1, v2, v3);
                                         else *reinterpret_cast<float4*>(yout + ml * HW + (row0 + r) * W + px0 + 4 * l15) = make_float4(v0, v1, v2, v3);
                                         fs[q] += (v0 + v1) + (v2 + v3);
                                         fq[q] = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, fq[q]))));
@@ -607,20 +611,21 @@ __global__ __launch_bounds__(512, MINW) void conv_rp_kernel(RpArgs A)
     }
 }
 
-template <int MODE, int MF, int R, bool REM, int KS, bool W32 = false>
+template <int MODE, int MF, int R, bool REM, int KS, int WSH = 0>
 int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
 {
-    using Cfg = RpCfg<R, MODE, W32>;
+    using Cfg = RpCfg<R, MODE, WSH>;
+    constexpr bool W32 = WSH > 0; constexpr int QPR = Cfg::QPR, NSUB = Cfg::NSUB;
     const ConvGeom& g = A.g;
     const int MOUT = MODE == 0 ? g.Cout : g.Cin;
     constexpr int CT = 16 * MF;
-    if (g.H % (W32 ? 2 * Cfg::TH : Cfg::TH)) return -3;
+    if (g.H % (W32 ? NSUB * Cfg::TH : Cfg::TH)) return -3;
     const int RED = MODE == 0 ? g.Cin : g.Cout;
     if (RED % (4 * KS)) return -3;
     if (MODE == 1 && RED / (4 * KS) < 4) return -3;       // the fold of a tile rides on stages 0..2 of the next one
     if (REM && !((MOUT & 15) == 4 && (MOUT - 4) % CT == 0)) return -3;
     A.tiles_x = W32 ? 1 : g.W / 64;
-    A.n_tiles = W32 ? g.H / (2 * Cfg::TH) : A.tiles_x * (g.H / Cfg::TH);
+    A.n_tiles = W32 ? g.H / (NSUB * Cfg::TH) : A.tiles_x * (g.H / Cfg::TH);
     A.tiles_per_block = T;
     { static const int il = [] { const char* e = getenv("MFVI_RP_INTERLEAVE"); return !(e && e[0] == '0'); }(); A.interleave = il; }
     A.nx = (A.n_tiles + T - 1) / T; A.ny = REM ? (MOUT - 4) / CT : (MOUT + CT - 1) / CT; A.nz = n_samples;
@@ -628,7 +633,7 @@ int launch_rp(RpArgs& A, int T, int n_samples, hipStream_t st)
     const size_t dyn = sizeof(float) * 2 * WCH + sizeof(ChanFwd) * (size_t)((g.Cin + 3) & ~3) + sizeof(RpBwd) * (size_t)((g.Cout + 3) & ~3);
     constexpr int MINW = 4;
     mfvi_tl_family = 2;
-    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, KS, MINW, W32>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
+    mfvi_launch((conv_rp_kernel<MODE, MF, R, REM, KS, MINW, WSH>), dim3(A.nx * A.ny * A.nz), dim3(512), dyn, st, A);
     return (int)hipGetLastError();
 }
 
@@ -641,13 +646,33 @@ int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
 #define RP_GO(MF_, R_) RP_GO2(MF_, R_, 1)      /* two k-steps per stage (KS = 2) built and measured: no gain, register spills in backward-data; not instantiated */
     if (A.g.W == 32) {      // maps 32 wide: two image rows per 64-pixel strip
         if constexpr (MODE == 0) {
-#define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1 && !rem) return launch_rp<0, MF_, R_, false, 1, true>(A, T, n_samples, st);
+#define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1 && !rem) return launch_rp<0, MF_, R_, false, 1, 3>(A, T, n_samples, st);
             RP_GO32(1, 1) RP_GO32(1, 2) RP_GO32(2, 1) RP_GO32(2, 2) RP_GO32(4, 1) RP_GO32(1, 4)
 #undef RP_GO32
         } else {
-#define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1) { if (rem) return launch_rp<1, MF_, R_, true, 1, true>(A, T, n_samples, st); return launch_rp<1, MF_, R_, false, 1, true>(A, T, n_samples, st); }
+#define RP_GO32(MF_, R_) if (mf == MF_ && r == R_ && ks == 1) { if (rem) return launch_rp<1, MF_, R_, true, 1, 3>(A, T, n_samples, st); return launch_rp<1, MF_, R_, false, 1, 3>(A, T, n_samples, st); }
             RP_GO32(1, 1) RP_GO32(1, 2) RP_GO32(2, 1)
 #undef RP_GO32
+        }
+        return -3;
+    }
+    if (A.g.W == 16) {      // maps 16 wide: four image rows per strip (a 16 x 16 map is ONE tile of 4-row groups)
+        if constexpr (MODE == 0) {
+#define RP_GO16(MF_, R_) if (mf == MF_ && r == R_ && ks == 1 && !rem) return launch_rp<0, MF_, R_, false, 1, 2>(A, T, n_samples, st);
+            RP_GO16(1, 1) RP_GO16(2, 1) RP_GO16(4, 1) RP_GO16(1, 2) RP_GO16(2, 2)
+#undef RP_GO16
+            // one 16 x 16 map = one tile per block and 32 stages of 4 channels: a latency chain of ~1.2 us per stage (barrier, LDS round
+            // trip, load latency) with nothing else on the CU to hide it -> 2 or 4 k-steps per stage
+#define RP_GO16K(MF_, KS_) if (mf == MF_ && r == 1 && ks == KS_ && !rem) return launch_rp<0, MF_, 1, false, KS_, 2>(A, T, n_samples, st);
+            RP_GO16K(1, 2) RP_GO16K(1, 4) RP_GO16K(2, 2) RP_GO16K(2, 4)
+#undef RP_GO16K
+        } else {
+#define RP_GO16K(MF_, KS_) if (mf == MF_ && r == 1 && ks == KS_) { if (rem) return launch_rp<1, MF_, 1, true, KS_, 2>(A, T, n_samples, st); return launch_rp<1, MF_, 1, false, KS_, 2>(A, T, n_samples, st); }
+            RP_GO16K(1, 2) RP_GO16K(1, 4) RP_GO16K(2, 2)
+#undef RP_GO16K
+#define RP_GO16(MF_, R_) if (mf == MF_ && r == R_ && ks == 1) { if (rem) return launch_rp<1, MF_, R_, true, 1, 2>(A, T, n_samples, st); return launch_rp<1, MF_, R_, false, 1, 2>(A, T, n_samples, st); }
+            RP_GO16(1, 1) RP_GO16(2, 1) RP_GO16(1, 2)
+#undef RP_GO16
         }
         return -3;
     }
@@ -663,7 +688,7 @@ int dispatch_rp(RpArgs& A, int tune, int n_samples, hipStream_t st)
 // Returns -2 when the shape is not served by the row-phase kernels, -3 when the tiling is not valid for it.
 int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st)
 {
-    if (g.ks != 3 || g.stride != 1 || ((g.W & 63) && g.W != 32) || (g.H & 3) || (g.Cin & 3) || (g.w_off & 3) || g.Cin > MFVI_MAX_C) return -2;
+    if (g.ks != 3 || g.stride != 1 || ((g.W & 63) && g.W != 32 && g.W != 16) || (g.H & 3) || (g.Cin & 3) || (g.w_off & 3) || g.Cin > MFVI_MAX_C) return -2;
     if ((in.sstride & 3) || ((uintptr_t)in.data & 15) || (out.sstride & 3) || ((uintptr_t)out.data & 15)) return -2;
     if (in.act & MFVI_ACT_SQUARE) return -2;                                          // variance convolution of the LRT layers: round-2 kernels
     if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 29)) return -2;          // 32-bit element offsets per sample, two flag bits
@@ -674,7 +699,7 @@ int launch_conv_fwd_rp(const TView& in, const ConvGeom& g, const float* w, long 
 
 int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse)
 {
-    if (g.ks != 3 || g.stride != 1 || ((g.W & 63) && g.W != 32) || (g.H & 3) || g.H < 4 || (g.Cin & 3) || (g.Cout & 3) || (g.w_off & 3) || g.Cout > MFVI_MAX_C || g.Cin > MFVI_MAX_C) return -2;
+    if (g.ks != 3 || g.stride != 1 || ((g.W & 63) && g.W != 32 && g.W != 16) || (g.H & 3) || g.H < 4 || (g.Cin & 3) || (g.Cout & 3) || (g.w_off & 3) || g.Cout > MFVI_MAX_C || g.Cin > MFVI_MAX_C) return -2;
     if (!fuse.ga || (fuse.ga_sstride & 3) || ((uintptr_t)fuse.ga & 15) || g.Cout < 16) return -2;      // the fold of a tile rides on stages 0..2 of the next one
     if ((gy.gstride & 3) || ((uintptr_t)gy.ga & 15) || (gy.stats && ((gy.ystride & 3) || ((uintptr_t)gy.y & 15)))) return -2;
     if (fuse.bsums && ((fuse.x.sstride & 3) || ((uintptr_t)fuse.x.data & 15))) return -2;
@@ -690,7 +715,7 @@ int launch_conv_bwd_data_rp(const GView& gy, const ConvGeom& g, const float* w, 
 int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
 {
     static const int on = [] { const char* e = getenv("MFVI_RP"); return !(e && e[0] == '0'); }();
-    if (!on || g.ks != 3 || g.stride != 1 || ((g.W & 63) && !(g.W == 32 && (g.H & 7) == 0)) || (g.H & 3)) return 0;
+    if (!on || g.ks != 3 || g.stride != 1 || ((g.W & 63) && !(g.W == 32 && (g.H & 7) == 0) && !(g.W == 16 && (g.H & 15) == 0)) || (g.H & 3)) return 0;
     static const int forced = [] { int mf = 0, r = 0, T = 1, rem = 0, ks = 1; const char* e = getenv("MFVI_TUNE_RP"); if (e) sscanf(e, "%d,%d,%d,%d,%d", &mf, &r, &T, &rem, &ks); return mf > 0 ? (mf | r << 8 | (rem & 1) << 12 | (ks & 7) << 13 | T << 16) : 0; }();
     if (forced) return forced | MFVI_TUNE_RP;
     const int MOUT = mode == 0 ? g.Cout : g.Cin;
@@ -699,7 +724,7 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
     if (mo < 16) return 0;
     if (mode == 1 && g.Cout < 16) return 0;
     const int mf = (mo % 32 == 0) ? 2 : 1;
-    const long long units = (long long)max(1, g.W / 64) * (g.H / (g.W == 32 ? 8 : 4)) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles, one per block
+    const long long units = (long long)max(1, g.W / 64) * (g.H / (g.W == 32 ? 8 : g.W == 16 ? 16 : 4)) * ((mo + 16 * mf - 1) / (16 * mf)) * n_samples;      // blocks with 4-row tiles, one per block
     // measured on the three big layers (profiles/r03_rp_layers.txt): forward — tall tiles (fewer stage barriers per MFMA) while the grid
     // still fills the chip twice; backward-data — 4-row tiles (the out tile of the fold is LDS) and several tiles per block (the last
     // tile's fold and the block prologue are exposed once per block)

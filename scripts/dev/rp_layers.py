@@ -62,10 +62,10 @@ for cin, cout, hw in specs:
     for w, name, ps in ((0, "fwd", 0), (1, "bwd_data", 2)):
         for mf, r in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (4, 1)):
             for rem in ((0, 1) if (w == 1 and rem_ok) else (0,)):
-                for T, ks in [(T_, k_) for T_ in (1, 2, 4, 8, 16) for k_ in (1, 2)]:
+                for T, ks in [(T_, k_) for T_ in (1, 2, 4, 8, 16) for k_ in (1, 2, 4)]:
                     if sel is not None and (w, mf, r, T, rem, ks) not in sel:
                         continue
-                    if sel is None and (T > 4 or ks > 1):
+                    if sel is None and (T > 4 or (ks > 1 and not (hw == 16 and T == 1 and r == 1))):
                         continue
                     code = mf | r << 8 | rem << 12 | ks << 13 | T << 16 | RP
                     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, w, code))
