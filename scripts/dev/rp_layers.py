@@ -51,6 +51,14 @@ for cin, cout, hw in specs:
     for w, name, ps in ((0, "fwd", 0), (1, "bwd_data", 2), (2, "bwd_weight", 1)):
         us = measure(plan, P, op, bufs, ps)
         print("%d->%d @%d %-10s autotuned %#x: %7.1f us %5.1f TF (%.3f)" % (cin, cout, hw, name, base[w], us, tf(us), tf(us) / 157.3), flush=True)
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, 1 | 1 << 26))      # small-map forward (conv_small.hip)
+    try:
+        us = measure(plan, P, op, bufs, 0)
+        if lib.mfvi_plan_last_kernel(plan.handle, op, 0) == 4:
+            print("%d->%d @%d %-10s small-map kernel: %7.1f us %5.1f TF (%.3f)" % (cin, cout, hw, "fwd", us, tf(us), tf(us) / 157.3), flush=True)
+    except M._lib.MfviError:
+        pass
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, base[0]))
     rem_ok = (cin & 15) == 4
     only = os.environ.get("RP_ONLY")      # e.g. "0:1,4,1,0;1:2,1,2,1" = pass:mf,r,T,rem
     sel = None
