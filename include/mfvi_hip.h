@@ -186,7 +186,7 @@ int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
  * VALU kernels (also: a tiling the shape does not admit falls back to them), 1 = fp32 MFMA kernels, 2 = row-phase fp32 MFMA kernels
  * (3x3 stride 1, maps a multiple of 64 wide or exactly 32 / 16 wide), 3 = bf16x6 kernels (fp32 operands as three bf16 pieces on the bf16
  * matrix instruction: forward tune bit 25 = mf | rows << 8 | strips per block << 16; backward-weight w = 11, input tiles field = output
- * fragments per block), 4 = small-map forward (3x3 stride 1 on 8- / 16-wide maps, <= 144 input channels: tune = 1 | 1 << 26; the whole
+ * fragments per block), 4 = small-map forward / backward-data (3x3 stride 1 on 8- / 16-wide maps, <= 144 reduction channels: tune = 1 | 1 << 26; the whole
  * reduction of a block in LDS, one stage).  -1: bad arguments.  Tests use it to prove that the kernel under test is the one that ran. */
 int mfvi_plan_last_kernel(const mfvi_plan* plan, int op, int which);
 

@@ -388,6 +388,7 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not 
 // small-map forward (conv_small.hip): the whole reduction of a (sample, 16 output channels, 64 pixels) block in LDS, one stage; tune bit 26
 #define MFVI_TUNE_SM (1 << 26)
 int launch_conv_fwd_small(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
+int launch_conv_bwd_data_small(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int n_samples, hipStream_t st, const FoldFuse& fuse);
 extern thread_local float* mfvi_tl_x6w;
 extern thread_local bool mfvi_tl_x6w_ready;      // the pieces of this pass are already in the scratch (launch_x6_split_all)
 long long x6_fwd_scratch_floats(const ConvGeom& g, int n_samples);

@@ -1222,6 +1222,10 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
         if (g.ks == 3 && (g.H < 4 || g.W < 4)) return -2;      // rows 1 and H-2 (columns 1 and W-2) must be distinct, interior lines
         if (g.ks == 3) {
             const int tn = g.tune[1] ? g.tune[1] : (env_tune() ? 0 : rp_default_tune(g, 1, n_samples));
+            if (tn & MFVI_TUNE_SM) {      // small-map kernel (conv_small.hip): only as an explicit tiling of the plan / autotuner
+                const int rc = launch_conv_bwd_data_small(gy, g, w, wstride, n_samples, st, *fuse);
+                return rc == -2 ? -3 : rc;
+            }
             if (tn & MFVI_TUNE_RP) {
                 const int rc = launch_conv_bwd_data_rp(gy, g, w, wstride, tn & (MFVI_TUNE_RP - 1), n_samples, st, *fuse);
                 if (rc != -2 || g.tune[1]) return rc == -2 ? -3 : rc;

@@ -1096,7 +1096,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                     for (int mf : {1, 2}) for (int ks : {2, 4}) for (int rem = 0; rem <= ((which == 1 && (o.g.Cin & 15) == 4) ? 1 : 0); ++rem)
                         cands.push_back(mf | 1 << 8 | rem << 12 | ks << 13 | 1 << 16 | MFVI_TUNE_RP);
                 // small-map forward (conv_small.hip): one stage, the block's whole reduction in LDS
-                if (which == 0 && o.g.ks == 3 && o.g.stride == 1 && o.g.W <= 16) cands.push_back(1 | MFVI_TUNE_SM);
+                if (which <= 1 && o.g.ks == 3 && o.g.stride == 1 && o.g.W <= 16) cands.push_back(1 | MFVI_TUNE_SM);
                 // bf16x6 forward (conv_x6.hip): output fragments per block, 8 output rows per block
                 if (which == 0 && o.x6w_off >= 0) for (int mf : {1, 2}) for (int T = 1; T <= 16; T *= 2) cands.push_back(mf | 8 << 8 | T << 16 | MFVI_TUNE_X6);
             }

@@ -59,6 +59,14 @@ for cin, cout, hw in specs:
     except M._lib.MfviError:
         pass
     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, base[0]))
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 1, 1 | 1 << 26))      # small-map backward-data
+    try:
+        us = measure(plan, P, op, bufs, 2)
+        if lib.mfvi_plan_last_kernel(plan.handle, op, 1) == 4:
+            print("%d->%d @%d %-10s small-map kernel: %7.1f us %5.1f TF (%.3f)" % (cin, cout, hw, "bwd_data", us, tf(us), tf(us) / 157.3), flush=True)
+    except M._lib.MfviError:
+        pass
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 1, base[1]))
     rem_ok = (cin & 15) == 4
     only = os.environ.get("RP_ONLY")      # e.g. "0:1,4,1,0;1:2,1,2,1" = pass:mf,r,T,rem
     sel = None

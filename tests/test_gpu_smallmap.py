@@ -69,3 +69,25 @@ def test_smallmap_tiling_on_a_wide_map_falls_back(M):
     z = torch.zeros
     plan.forward(z(P.n_vi, device="cuda"), z(P.n_vi, device="cuda"), z(1, device="cuda"), z(16 * 16 * 64, device="cuda"), 1, 0, 0, 1)
     assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) == 0
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 8, 8), (132, 128, 16, 16), (128, 128, 16, 16), (36, 16, 16, 16), (64, 64, 32, 16), (16, 32, 8, 8), (20, 16, 24, 8),
+                                   (68, 32, 4, 16), (16, 16, 64, 16)])
+def test_smallmap_backward_data_inside_a_plan(M, shape):
+    """Fused-fold backward-data of the small-map kernel: BN-backward on load, zero padding, the reflection adjoint through spare window rows /
+    columns (rows 1 and H-2 in one tile on 8-row maps, in the first / last tile otherwise; corners), a partial last output fragment
+    (132 = 8 x 16 + 4 channels), LeakyReLU' + BN-backward sums of the input tensor in the epilogue.  Against the round-2 tiling."""
+    cin, cout, H, W = shape
+    n, seed = 2, 101
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, enc(1, 8, 1))); M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, SM))
+    got = _run_plan(plan, P, seed, n, z, dout)
+    assert lib.mfvi_plan_last_kernel(plan.handle, 1, 1) == 4
+    assert relerr(got[0], ref[0]) < 1e-6
+    for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+        assert relerr(a, b) < 2e-5, name
