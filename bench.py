@@ -6,7 +6,8 @@ One step = one tempered-ELBO iteration: input perturbation, weight draw, K MC fo
 N > 1 ranks, the single all-reduce of the flat gradient buffer).
 
     python bench.py [--gpus N --steps K --warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg5|inp] [--scaling weak|strong] [--k K] [--mode engine|dropin]
-                                                   (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+      N > 1: one rank per GPU over RCCL — under torch.distributed.run (the driver's launch line: RANK / LOCAL_RANK / WORLD_SIZE /
+      MASTER_* come from the environment), or started plainly, in which case this process spawns the N ranks itself (self_launch).
 
 --mode engine (default): the fused runner (ElboEngine: ~10 library calls per iteration, no autograd).
 --mode dropin: the loop a user of the reference runs after INTEGRATION.md's three-line switch — get_net + MeanFieldVI(n_samples=K) +
@@ -155,6 +156,131 @@ def cpu_baseline(cfg, n_samples):
                        % (n_samples, S, S, task, cores, dt))
 
 
+def unfused_gpu_baseline(cfg, K, torch, steps=20, warmup=5, max_passes=480, device="cuda"):
+    """SURVEY.md 8(d)'s same-node comparison row: the SAME iteration out of stock PyTorch-ROCm ops (MIOpen / ATen kernels, autograd,
+    torch.optim.AdamW), float32, on the GPU this benchmark runs on.  The net is this package's own plain-torch module tree
+    (nets.get_net, executable as is); every nn.Conv2d in it is swapped for a small module written here that holds (mu, rho) and runs
+    w = mu + softplus(rho) * randn_like(mu), F.conv2d(x, w, b) — what BayTorch/modules/reparam_layers.py:26-37 does, restated, not the
+    reference's file.  One iteration = the reference's loop body (bayesian_optimization.py:1360-1372) with K sequential batch-1 forwards on
+    the same perturbed input and the loss averaged, the closed-form reverse KL of every layer, backward, AdamW(wd = 0).
+    Untimed by the contract; `steps` iterations after `warmup` (MIOpen's kernel search runs in the warm-up), fewer when K is large."""
+    import math
+    import numpy as np
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from mfvi_dip_mia_amd import nets
+    from mfvi_dip_mia_amd.engine import INP_NET
+    from mfvi_dip_mia_amd.runner import phantom
+    S, hp, task = cfg["size"], cfg["hp"], cfg["task"]
+    dev = torch.device(device)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    prior_sigma = float(np.float32(math.sqrt(hp["temp"]) * hp["sigma"] + 1e-6))
+
+    class ReparamConv(nn.Module):
+        def __init__(self, conv):
+            super().__init__()
+            self.stride = conv.stride
+            self.W_mu = nn.Parameter(torch.randn_like(conv.weight) * 0.1)
+            self.W_rho = nn.Parameter(torch.randn_like(conv.weight) * 0.1 - 3.0)
+            self.bias_mu = nn.Parameter(torch.randn_like(conv.bias) * 0.1)
+            self.bias_rho = nn.Parameter(torch.randn_like(conv.bias) * 0.1 - 3.0)
+
+        def forward(self, x):
+            w = self.W_mu + F.softplus(self.W_rho) * torch.randn_like(self.W_mu)
+            b = self.bias_mu + F.softplus(self.bias_rho) * torch.randn_like(self.bias_mu)
+            return F.conv2d(x, w, b, self.stride)
+
+        def kl(self):      # KL(N(0, s0^2) || N(mu, s^2)) summed: log(s / s0) + (s0^2 + mu^2) / (2 s^2) - 1/2
+            t = 0.0
+            for m, r in ((self.W_mu, self.W_rho), (self.bias_mu, self.bias_rho)):
+                s = F.softplus(r)
+                t = t + (torch.log(s / prior_sigma) + (prior_sigma ** 2 + m * m) / (2 * s * s) - 0.5).sum()
+            return t
+
+    def swap(mod):
+        for name, ch in list(mod._modules.items()):
+            if isinstance(ch, nn.Conv2d):
+                mod._modules[name] = ReparamConv(ch)
+            else:
+                swap(ch)
+
+    torch.manual_seed(hp["seed"])
+    n_out = {"ct": 1, "inp": 4}.get(task, 2)
+    if task == "inp":
+        kw = INP_NET
+        net = nets.skip(cfg["input_depth"], n_out, num_channels_down=list(kw["nd"]), num_channels_up=list(kw["nu"]), num_channels_skip=list(kw["ns"]),
+                        filter_size_down=kw["fd"], filter_size_up=kw["fu"], need1x1_up=kw["need1x1_up"], upsample_mode=kw["upsample_mode"],
+                        need_sigmoid=False, need_bias=True, pad='reflection', dropout_mode_down='None', dropout_mode_up='None')
+    else:
+        net = nets.get_net(cfg["input_depth"], 'skip', 'reflection', 'bilinear', n_channels=n_out, skip_n33d=[16, 32, 64, 128, 128],
+                           skip_n33u=[16, 32, 64, 128, 128], skip_n11=4, num_scales=5)
+    net = net.to(dev)
+    swap(net)
+    layers = [m for m in net.modules() if isinstance(m, ReparamConv)]
+    opt = torch.optim.AdamW(net.parameters(), lr=hp["lr"], weight_decay=0)
+    rng = np.random.default_rng(hp["seed"] + 1)
+    img = torch.from_numpy(phantom(S, S, hp["seed"])).to(dev)[None, None]
+    z0 = 0.1 * torch.rand((1, cfg["input_depth"], S, S), device=dev)
+    if task == "den":
+        target = torch.clamp(img + hp["p_sigma"] * torch.randn_like(img), 0, 1)
+    elif task == "sr":
+        target = img[..., ::4, ::4].contiguous()
+    elif task == "ct":      # 45 rotations, bilinear sampling with zero padding, summed over the rows (radon/radon.py:23-55 restated)
+        th = torch.deg2rad(torch.arange(0., 180., 4., device=dev))
+        rot = torch.stack([torch.stack([th.cos(), -th.sin(), torch.zeros_like(th)], 1), torch.stack([th.sin(), th.cos(), torch.zeros_like(th)], 1)], 1)
+        grid = F.affine_grid(rot, (th.numel(), 1, S, S), align_corners=False)
+        radon = lambda x: F.grid_sample(x.expand(th.numel(), -1, -1, -1), grid, mode='bilinear', padding_mode='zeros', align_corners=False).sum(2).transpose(0, 1)[None]
+        target = radon(img)
+    else:
+        img = torch.from_numpy(np.stack([phantom(S, S, hp["seed"] + c) for c in range(3)])).to(dev)[None]
+        mask = torch.from_numpy((rng.random((1, 1, S, S)) > 0.12).astype(np.float32)).to(dev)
+
+    def data_term(out):
+        if task == "ct":
+            return F.mse_loss(radon(out), target)
+        if task == "inp":      # utils/bayesian_utils.py:35-39: masked heteroscedastic NLL on the sigmoid of the colour logits
+            s = torch.clamp(out[:, 3:], -20, 20)
+            return ((torch.exp(s) * (img - torch.sigmoid(out[:, :3])) ** 2 - s) * mask).mean()
+        o = out[..., ::4, ::4] if task == "sr" else out
+        s = torch.clamp(o[:, 1:], -20, 20)
+        return (torch.exp(s) * (target - o[:, :1]) ** 2 - s).mean()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        z = z0 + 0.1 * torch.randn_like(z0)
+        nll = 0.0
+        for _ in range(K):      # K sequential batch-1 forwards; each backward frees its graph (the sum of the gradients is the gradient of the mean)
+            l = data_term(net(z)) / K
+            l.backward()
+            nll = nll + l.detach()
+        kl = sum(m.kl() for m in layers)
+        (hp["temp"] * kl).backward()
+        opt.step()
+        return nll, kl
+
+    steps = max(3, min(steps, max_passes // max(K, 1)))
+    for _ in range(warmup):
+        step()
+    sync(); t0 = time.perf_counter()
+    for _ in range(steps):
+        nll, kl = step()
+    sync(); dt = time.perf_counter() - t0
+    n_launch = None
+    try:      # launches per iteration, from the profiler's kernel records of ONE more iteration (information only)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step(); sync()
+        n_launch = sum(e.count for e in prof.key_averages() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower())
+    except Exception:
+        n_launch = None
+    return dict(ms_per_iteration=1e3 * dt / steps, value=K * steps / dt, unit="MC-forward-passes/s", elbo_iters_per_sec=steps / dt,
+                steps=steps, warmup=warmup, dtype="f32", kernel_launches_per_iteration=n_launch,
+                final_nll=float(nll), final_kl=float(kl.detach()),
+                what="stock PyTorch-ROCm ops on the same GPU: nets.get_net module tree, plain-torch reparam conv (w = mu + softplus(rho) * randn), "
+                     "K sequential batch-1 forwards + autograd + closed-form KL + torch.optim.AdamW, MIOpen warm (%d warm-up iterations)" % warmup,
+                software="torch %s" % torch.__version__)
+
+
 def make_engine(cfg, K, rank, world, torch):
     """Engine + synthetic target of a config, inputs from the package's own generator (runner.phantom)."""
     import numpy as np
@@ -243,6 +369,49 @@ class DropInLoop:
         return None
 
 
+def child_commands(n, argv, env, port=None):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): the N per-rank child processes the parent starts,
+    as a list of (argv, env) — one fresh interpreter per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line.
+    Same shape as the reference's fan-out, which spawns its own children one per device (bayesian_optimization.py:3760-3775)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = []
+    for r in range(n):
+        e = dict(env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out.append(([sys.executable, os.path.abspath(__file__)] + list(argv), e))
+    return out
+
+
+def self_launch(n, argv):
+    """Parent of a plain `python bench.py --gpus N`: starts the ranks as child processes (never exec, never touches the GPU itself),
+    relays rank 0's stdout (the ONE JSON line) and every rank's stderr, waits for all of them; exit code = first non-zero child code.
+    A rank that dies takes the others down (they would otherwise wait in the rendezvous / a collective for ever)."""
+    import subprocess
+    procs = []
+    for r, (cmd, env) in enumerate(child_commands(n, argv, os.environ)):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +424,7 @@ def main():
     ap.add_argument("--mode", default="engine", choices=["engine", "dropin"])
     ap.add_argument("--flat-parameters", action="store_true", help="--mode dropin: MeanFieldVI(..., flat_parameters=True) (one flat Parameter for the optimizer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-baseline", action="store_true", help="skip the unfused PyTorch-ROCm leg (SURVEY 8d's same-node row)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel time table of one iteration to stderr")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -263,13 +433,17 @@ def main():
     if args.k:
         cfg["k"] = args.k; cfg.pop("k_strong", None)
 
+    # started plainly with --gpus N > 1 (no launcher in front): this process becomes the parent of N ranks — decided before torch is
+    # imported or the GPU touched (a process that has initialised the GPU must not be replaced, and is not: children are spawned)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d inside a %d-rank job (WORLD_SIZE): the two must agree" % (args.gpus, world))
     # MFVI_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks on ONE GPU (RCCL refuses duplicate devices); the
     # driver's runs use the default: one rank per GPU over RCCL
     backend = os.environ.get("MFVI_BENCH_BACKEND", "nccl")
@@ -424,6 +598,8 @@ def main():
         iso_ms = by[(dom_op, dom_pass)] / n_launch
         roof["alone"] = dict(avg_launch_ms=iso_ms, achieved=(cost["flops"] / 1e12 if roof["bound"] == "mfma" else cost["bytes"] / 1e9) / (iso_ms * 1e-3),
                              frac=(cost["flops"] / 1e12 if roof["bound"] == "mfma" else cost["bytes"] / 1e9) / (iso_ms * 1e-3) / roof["peak"])
+        if world > 1 and backend != "nccl":      # the one-GPU rehearsal (MFVI_BENCH_BACKEND=gloo): the ranks share the chip, no kernel runs alone
+            roof["alone"] = None
         roof["note"] = ("achieved/frac: launch duration inside the timed region, where the backward-weight kernels run on the plan's low-priority side "
                         "stream and share the chip with the backward-data / concat chain of the caller's stream (the overlap shortens the "
                         "iteration and stretches the individual launches); 'alone': the same kernel in the untimed instrumented iteration, side "
@@ -486,8 +662,17 @@ def main():
             res["allreduce_overlap"] = overlap
         if cfg["task"] == "den" and S == 256:
             res["reference_cpu_probe"] = REFERENCE_CPU_PROBE
+        k_local = eng.K_local
+        if world == 1 and not args.no_gpu_baseline:
+            try:
+                del eng
+                torch.cuda.empty_cache()
+                res["unfused_gpu_baseline"] = unfused_gpu_baseline(cfg, K_total, torch)
+                res["unfused_gpu_baseline"]["speedup_of_this_path"] = res["unfused_gpu_baseline"]["ms_per_iteration"] / res["ms_per_step"]
+            except Exception as ex:      # a baseline leg must never take the benchmark line down
+                res["unfused_gpu_baseline"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if args.mode == "dropin":
-            res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(cfg, min(cfg["cpu_samples"], 8 * max(1, eng.K_local)))
+            res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(cfg, min(cfg["cpu_samples"], 8 * max(1, k_local)))
         elif world == 1 and not args.no_cpu_baseline and cfg["cpu_samples"]:
             res["cpu_baseline"] = cpu_baseline(cfg, cfg["cpu_samples"])
         elif world == 1 and not args.no_cpu_baseline:
