@@ -432,10 +432,8 @@ class MeanFieldVI(nn.Module):
         bn_eval = bool(self._bn) and not self._bn[0].training
         if bn_eval and not all(b.track_running_stats for b in self._bn):
             raise NotImplementedError("BatchNorm2d(track_running_stats=False) in eval mode")
-        if bn_eval and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # fail here, not later inside autograd: the kernels implement the training-mode BatchNorm backward only
-            raise NotImplementedError("backward through eval-mode BatchNorm is not built (the reference never trains in eval mode): "
-                                      "call the net under torch.no_grad() in eval mode, or switch it back with .train()")
+        # (a plain `net.eval(); y = net(x)` outside torch.no_grad() is ordinary notebook usage and works forward-only; what is not built — the
+        #  backward through eval-mode BatchNorm — is refused where it is asked for: _check_token, called by both wrappers' backward)
         # module.eval(): running statistics instead of batch statistics (forward only; the reference never trains in eval mode)
         L.check(L.lib().mfvi_plan_set_bn_eval(plan.handle, L.ptr(self._running) if bn_eval else None))
         out = plan.forward(mu, rho, bn, x3, self.seed, step, 0, self.n_samples, sample)
@@ -449,13 +447,21 @@ class MeanFieldVI(nn.Module):
         self._token += 1
         if sample or dropping:
             self._step += 1                  # fresh eps / dropout masks for every call, like randn_like in VIModule.rsample
-        return out, (self._token, plan, x3, step, sample)
+        return out, (self._token, plan, x3, step, sample, bn_eval)
+
+    def _check_token(self, token):
+        """The forward a backward call belongs to must be the latest one (one workspace per plan) and a training-mode one."""
+        tok, plan, x3, step, sample, bn_eval = token
+        if tok != self._token:
+            raise RuntimeError("backward through a MeanFieldVI / FusedNet forward that is no longer the latest one: the activations live in one "
+                               "workspace per plan.  Draw K Monte-Carlo samples in ONE call (n_samples=K) instead of K calls.")
+        if bn_eval:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not built (the reference never trains in eval mode): "
+                                      "call .train() before a forward whose gradients are needed")
+        return plan, x3, step, sample
 
     def _hip_backward(self, token, dout, want_dz, flat=False):
-        tok, plan, x3, step, sample = token
-        if tok != self._token:
-            raise RuntimeError("backward through a MeanFieldVI forward that is no longer the latest one: the activations live in one "
-                               "workspace per plan.  Draw K Monte-Carlo samples in ONE call (n_samples=K) instead of K calls.")
+        plan, x3, step, sample = self._check_token(token)
         mu, rho, bn = self._blocks()
         g = torch.zeros(2 * self.n_vi + max(self.n_bn, 1), dtype=torch.float32, device=self.device)
         n = self.n_vi
@@ -631,9 +637,7 @@ class FusedNet(MeanFieldVI):
         return self
 
     def _hip_backward(self, token, dout, want_dz):
-        tok, plan, x3, step, sample = token
-        if tok != self._token:
-            raise RuntimeError("backward through a forward that is no longer the latest one: the activations live in one workspace per plan")
+        plan, x3, step, sample = self._check_token(token)
         mu, rho, bn = self._blocks()
         g = torch.zeros(2 * self.n_vi + max(self.n_bn, 1), dtype=torch.float32, device=self.device)
         n = self.n_vi

@@ -1195,7 +1195,9 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
         }
         if (tn & MFVI_TUNE_RP) {
             const int rc = launch_conv_fwd_rp(in, g, w, wstride, out, tn & (MFVI_TUNE_RP - 1), n_samples, st);
-            if (rc != -2 || (g.tune[0] & MFVI_TUNE_RP)) return rc == -2 ? -3 : rc;
+            // an explicit tiling of the plan answers for itself (-3); a heuristic one the shape does not admit falls through to the round-2 tiles
+            if (g.tune[0] & MFVI_TUNE_RP) return rc == -2 ? -3 : rc;
+            if (rc != -2 && rc != -3) return rc;
         }
     }
     GView none{};
@@ -1228,7 +1230,8 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
             }
             if (tn & MFVI_TUNE_RP) {
                 const int rc = launch_conv_bwd_data_rp(gy, g, w, wstride, tn & (MFVI_TUNE_RP - 1), n_samples, st, *fuse);
-                if (rc != -2 || g.tune[1]) return rc == -2 ? -3 : rc;
+                if (g.tune[1]) return rc == -2 ? -3 : rc;
+                if (rc != -2 && rc != -3) return rc;      // (heuristic tiling not valid for this shape: the round-2 tiles below)
             }
         }
         if (g.ks == 3) return launch_variant<3, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);

@@ -729,9 +729,11 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples)
     // still fills the chip twice; backward-data — 4-row tiles (the out tile of the fold is LDS) and several tiles per block (the last
     // tile's fold and the block prologue are exposed once per block)
     int r = 1, T = 1;
+    // rows of a tile: 4 r image rows on the wide maps, NSUB * 4 r on the narrow ones (two / four image rows side by side): launch_rp's divisibility rule
+    const int rows1 = g.W == 32 ? 8 : g.W == 16 ? 16 : 4;
     if (mode == 0) {
-        if (mf == 1 && (g.H & 15) == 0 && units / 4 >= 1024) r = 4;
-        else if ((g.H & 7) == 0 && units / 2 >= 512) r = 2;
+        if (mf == 1 && g.H % (4 * rows1) == 0 && units / 4 >= 1024) r = 4;
+        else if (g.H % (2 * rows1) == 0 && units / 2 >= 512) r = 2;
     } else {
         while (T < 8 && units / (2 * T) >= 512) T *= 2;
     }

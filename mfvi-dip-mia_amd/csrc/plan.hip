@@ -84,7 +84,11 @@ struct mfvi_plan {
     // >= split_op on split_stream as soon as their backward-weight kernels have been enqueued, the rest at the end as before.  The early
     // group has its own half of the device table (fin_dev + n_conv).
     int split_op = -1; hipStream_t split_stream = nullptr; hipEvent_t split_ev[2] = {nullptr, nullptr}; int n_conv = 0;
-    std::vector<GradFinEntry> fin_uploaded_early;
+    // three tables, each with its own device slot (fin_dev + {0, 1, 2} * n_conv) and cached host copy: the whole pass (no split), the
+    // early group of a split pass, the late group of a split pass.  An engine that splits only the LAST launch of an iteration
+    // (K_local > samples per launch) alternates between "whole" and "early + late": with one slot shared by "whole" and "late" the cache
+    // missed twice per iteration, and the reassigned host vector was the source of a copy still in flight.
+    std::vector<GradFinEntry> fin_uploaded_early, fin_uploaded_late;
     // optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg)
     struct Rec { int op, pass; hipEvent_t a, b; };
     int prof_mode = 0, prof_op = -1, prof_pass = -1;      // 0 off, 1 every kernel, 2 only (prof_op, prof_pass)
@@ -265,7 +269,7 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
     p.total_bytes = p.float_base + fo * (long long)sizeof(float);
     if (n_conv) {
         p.n_conv = n_conv;
-        const hipError_t e = hipMalloc((void**)&p.fin_dev, sizeof(GradFinEntry) * n_conv * 2);      // second half: the early group of a gradient split
+        const hipError_t e = hipMalloc((void**)&p.fin_dev, sizeof(GradFinEntry) * n_conv * 3);      // whole pass | early group | late group of a gradient split
         if (e != hipSuccess) return fail("plan: hipMalloc of the gradient table failed: %s", hipGetErrorString(e));
     }
     p.n_entries = (int)table.size();
@@ -777,8 +781,10 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         for (auto& e : fin) { e.first_block = fin_blocks; fin_blocks += ((e.n_w >> 2) + ((e.n_b + 3) >> 2) + GRAD_FIN_QUADS - 1) / GRAD_FIN_QUADS; }
         ProfScope ps(plan, -1, PASS_GRAD_FINALIZE, fs);
         const bool same = fin.size() == uploaded.size() && memcmp(fin.data(), uploaded.data(), sizeof(GradFinEntry) * fin.size()) == 0;
-        if (!same) {      // tilings change only when the plan is (re)tuned: the table is uploaded once in steady state
+        if (!same) {      // tilings change only when the plan is (re)tuned: each of the three tables is uploaded once in steady state
             if (getenv("MFVI_DEBUG_FIN")) for (auto& e : fin) fprintf(stderr, "fin layer %d n_w %d strips %d first_block %d\n", e.layer_id, e.n_w, e.strips, e.first_block);
+            // the previous upload of this slot may still be reading the vector about to be reassigned (pageable source of an async copy)
+            if (!uploaded.empty()) (void)hipStreamSynchronize(fs);
             uploaded = fin;      // (the copy reads the plan-owned vector: `fin` is reused by the caller)
             const hipError_t e = hipMemcpyAsync(tab, uploaded.data(), sizeof(GradFinEntry) * uploaded.size(), hipMemcpyHostToDevice, fs);
             if (e != hipSuccess) { uploaded.clear(); set_error("backward: gradient table upload failed: %s", hipGetErrorString(e)); return (int)e; }
@@ -938,7 +944,10 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         if (e == hipSuccess) e = hipStreamWaitEvent(st, plan->join_event, 0);
         if (e != hipSuccess) { set_error("backward: join failed: %s", hipGetErrorString(e)); return (int)e; }
     }
-    { const int rc = finalize(st, plan->fin_dev, plan->fin_uploaded); if (rc) return rc; }
+    {   // the rest (or all) of the layers: the late group of a split pass has its own table slot
+        const bool was_split = plan->split_op >= 0 && plan->split_stream && plan->split_stream != st;
+        const int rc = was_split ? finalize(st, plan->fin_dev + 2 * plan->n_conv, plan->fin_uploaded_late) : finalize(st, plan->fin_dev, plan->fin_uploaded);
+        if (rc) return rc; }
     if (plan->n_lrt && sample_weights) {      // d rho += d sigma^2 * 2 softplus(rho) sigmoid(rho)
         const int rc = launch_lrt_drho(c.farena() + plan->dsig2_off, rho, plan->n_vi, drho, st);
         if (rc) { set_error("backward: lrt_drho launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }

@@ -194,7 +194,10 @@ class ElboEngine:
         a tail of the flat layout holding >= tail_fraction of the parameters — are complete when the backward pass (last op first) reaches
         the top scales of the down path; the plan reduces them on a second stream there (mfvi_plan_set_grad_split) and their all-reduce is
         enqueued on that stream, beside the rest of the pass.  The head of the layout, d BN and the NLL scalar follow in one packed
-        all-reduce after the pass.  Same sums in the same order either way: the update is bit-identical (tests/test_gpu_multirank.py)."""
+        all-reduce after the pass.  The same element-wise sums either way: with two ranks (one addition per element) the update is
+        bit-identical (tests/test_gpu_multirank.py); with more ranks a ring / tree collective cuts the three buffers of the split
+        schedule into other chunks than the one flat buffer, so the per-element order of the additions — and with it the last bit — may
+        differ between the two schedules.  bench.py records which schedule ran (`allreduce_overlap`); MFVI_AR_OVERLAP=0|1 pins it."""
         self._ov = None
         if not enabled:
             return

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import note_margin as _note
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +27,9 @@ def M():
 
 def relerr(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _v = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _note(_v, 'relerr')
+    return _v
 
 
 def dev(a):

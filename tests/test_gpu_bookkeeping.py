@@ -8,6 +8,8 @@ import types
 import numpy as np
 import pytest
 
+from conftest import note_margin as _note
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -17,7 +19,9 @@ torch = pytest.importorskip("torch")
 
 def relerr(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _v = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _note(_v, 'relerr')
+    return _v
 
 
 @pytest.fixture(scope="module")

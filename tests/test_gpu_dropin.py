@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import note_margin as _note
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -13,7 +15,9 @@ torch = pytest.importorskip("torch")
 
 def relerr(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _v = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _note(_v, 'relerr')
+    return _v
 
 
 @pytest.fixture(scope="module")
@@ -156,8 +160,10 @@ def test_batchnorm_running_statistics_and_eval_mode(M):
         o_eval = net(x); r_eval = plain(x)
     assert float((o_eval[0] - r_eval[0]).abs().max()) < 1e-4 * float(r_eval.abs().max())
     assert int(bn_w[0].num_batches_tracked) == 6                         # eval forwards leave the statistics alone
-    with pytest.raises(Exception, match="eval mode"):
-        net(x).sum().backward()
+    y_eval = net(x)                                                      # plain `net.eval(); y = net(x)` outside no_grad: forward-only use works
+    assert torch.equal(y_eval.detach(), o_eval)
+    with pytest.raises(NotImplementedError, match="eval mode"):          # ... and the backward nobody built is refused where it is asked for
+        y_eval.sum().backward()
     net.train()
     assert net(x).shape == (2, 2, 32, 32)
 

@@ -3,6 +3,8 @@
 import numpy as np
 import pytest
 
+from conftest import note_margin as _note
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -170,12 +172,16 @@ def _strided(a, n):
 
 def _relerr(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _v = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _note(_v, 'relerr')
+    return _v
 
 
 def _rel2(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    _v = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    _note(_v, 'rel-L2')
+    return _v
 
 
 @pytest.mark.parametrize("name", list(GOLD256))

@@ -5,6 +5,8 @@ w = mu + softplus(rho) * eps with the oracle's eps, train-mode BatchNorm, LeakyR
 import numpy as np
 import pytest
 
+from conftest import note_margin as _note
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +28,9 @@ def dev(a):
 
 def relerr(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _v = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _note(_v, 'relerr')
+    return _v
 
 
 def torch_program(P, zin, out_id, mu, rho, bn, z, seed, step, sample):

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import note_margin as _note
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -15,7 +17,9 @@ torch = pytest.importorskip("torch")
 
 def relerr(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _v = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    _note(_v, 'relerr')
+    return _v
 
 
 @pytest.fixture(scope="module")
@@ -214,7 +218,9 @@ def test_full_net_against_reference_golden(M, golden_dir, name, size):
     # max-norm loose.
     def rel2(a, b):
         a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        _v = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        _note(_v, 'rel-L2')
+        return _v
     gms, grs = gm[::st][:4096], gr[::st][:4096]
     print("full-net grad err vs f64 reference, max-norm: dmu %.2e drho %.2e dbn %.2e | L2: dmu %.2e drho %.2e | fp32 reference itself: max %.2e L2 %.2e" % (
         relerr(gms, g["dmu_s_f64"]), relerr(grs, g["drho_s_f64"]), relerr(host(dbn), g["dbn_f64"]), rel2(gms, g["dmu_s_f64"]),

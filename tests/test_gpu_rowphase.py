@@ -210,3 +210,25 @@ def test_rowphase_small_net_16_wide_against_oracle(M):
     # (nd = (16, 16, 32) with this seed has a LeakyReLU input within fp32 rounding of zero at the 16 x 16 level: the float64 oracle and any
     #  float32 kernel — round-2 kernels included — then take different branches of the derivative; scripts/dev/dbg_net_oracle.py)
     test_rowphase_small_nets_against_oracle(M, dict(H=64, W=64, input_depth=8, n_out=2, nd=(16, 32, 32), nu=(16, 32, 32), ns=(4, 4, 4)))
+
+
+@pytest.mark.parametrize("case", [(16, 64, 40, 32), (16, 128, 24, 32), (16, 64, 48, 16)])
+def test_heuristic_tiling_never_strands_a_layer(M, case):
+    """No tiling set on the plan (the heuristic of rp_default_tune answers) on narrow maps whose height the taller row-phase tiles do
+    not divide (W = 32, H = 40: tiles of 8 r rows need H % 16 == 0 for r = 2), many samples: the layer must stay on an MFMA kernel —
+    the heuristic's own tiling when valid, else the round-2 tiles — never drop to the generic fp32 kernels."""
+    cin, cout, H, W = case
+    seed, step, k0, n = 2500 + H + W, 1, 0, 16
+    P = M.Program()
+    zin = P.tensor(cin, H, W); out = P.tensor(cout, H, W); P.conv(zin, out, 3, 1)
+    plan = P.compile(zin, out, max_samples=n)
+    nw = cout * cin * 9
+    mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+    x = O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W)
+    lib = M._lib.lib()
+    y = host(plan.forward(dev(mu), dev(rho), torch.zeros(1, device="cuda"), dev(x), seed, step, k0, n))
+    assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) in (1, 2), "the layer fell off the MFMA kernels"
+    for i in (0, n - 1):
+        ew = O.eps(seed, step, k0 + i, 0, 0, nw); eb = O.eps(seed, step, k0 + i, 0, 1, cout)
+        w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, 3, 3); b = O.reparam(mu[nw:], rho[nw:], eb)
+        assert relerr(y[i], O.conv_fwd(x, w, b, 1)) < 2e-6, i
