@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmfvi_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_small.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
+SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_bwd_x6.hip", "conv_small.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
         if verbose and r.stderr:
             sys.stderr.write(r.stderr)
         return obj
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(one, SOURCES))
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
     if r.returncode != 0:

@@ -397,6 +397,16 @@ struct X6SplitEntry { long long w_off, dst_off; int Cin, Cout, COp, ncg, rem, un
 bool x6_split_entry(const ConvGeom& g, long long dst_off, X6SplitEntry* e);      // false: shape not served
 int launch_x6_split_all(const X6SplitEntry* table_dev, int n_entries, int n_blocks, const float* w, long long wstride, int n_k, float* arena, hipStream_t st);
 int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int tune, int n_samples, hipStream_t st);
+// Backward-data WITH the fold of the 3x3 stride-1 layers with 16 / 32 / 64 output channels on maps a multiple of 64 wide, on the bf16
+// matrix cores (conv_bwd_x6.hip).  tune = T | sr << 8 (strips per block, output rows per strip: 8 / 4 / 2 for 16 / 32 / 64 output channels).
+// Scratch for the split weight pieces: x6_bwd_scratch_floats() floats, handed over in mfvi_tl_x6bw around the launch (nullptr: -2).
+extern thread_local float* mfvi_tl_x6bw;
+extern thread_local bool mfvi_tl_x6bw_ready;
+long long x6_bwd_scratch_floats(const ConvGeom& g, int n_samples);
+struct X6BSplitEntry { long long w_off, dst_off; int CI, CO, NF, NG, k16, units, first_block, pad; };
+bool x6b_split_entry(const ConvGeom& g, long long dst_off, X6BSplitEntry* e);
+int launch_x6b_split_all(const X6BSplitEntry* table_dev, int n_entries, int n_blocks, const float* w, long long wstride, int n_k, float* arena, hipStream_t st);
+int launch_conv_bwd_data_x6(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse);
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
 // bf16: mu / rho point to bf16_t arrays; sample = 0 writes W = mu (RTLayer's eval branch) — callers then launch it for ONE sample

@@ -1223,7 +1223,15 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
         if (fuse->bsums && ((fuse->x.sstride & 3) || ((uintptr_t)fuse->x.data & 15))) return -2;
         if (g.ks == 3 && (g.H < 4 || g.W < 4)) return -2;      // rows 1 and H-2 (columns 1 and W-2) must be distinct, interior lines
         if (g.ks == 3) {
-            const int tn = g.tune[1] ? g.tune[1] : (env_tune() ? 0 : rp_default_tune(g, 1, n_samples));
+            int tn = g.tune[1] ? g.tune[1] : (env_tune() ? 0 : rp_default_tune(g, 1, n_samples));
+            if (tn & MFVI_TUNE_X6) {      // bf16x6 backward-data with the fold (conv_bwd_x6.hip): only as an explicit tiling of the plan / autotuner
+                const int rc = launch_conv_bwd_data_x6(gy, g, w, wstride, tn & (MFVI_TUNE_X6 - 1), n_samples, st, *fuse);
+                if (rc != -2) return rc;
+                // no scratch for the weight pieces in this call (w = mu without a weight draw): the layer's fp32 default
+                tn = env_tune() ? 0 : rp_default_tune(g, 1, n_samples);
+                if (tn & MFVI_TUNE_RP) { const int r2 = launch_conv_bwd_data_rp(gy, g, w, wstride, tn & (MFVI_TUNE_RP - 1), n_samples, st, *fuse); if (r2 != -2 && r2 != -3) return r2; }
+                return launch_variant<3, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
+            }
             if (tn & MFVI_TUNE_SM) {      // small-map kernel (conv_small.hip): only as an explicit tiling of the plan / autotuner
                 const int rc = launch_conv_bwd_data_small(gy, g, w, wstride, n_samples, st, *fuse);
                 return rc == -2 ? -3 : rc;

@@ -42,6 +42,7 @@ struct OpInfo {
     long long part_off = -1, part_stride = 0;  // floats: partial-dW slabs of the MFMA backward-weight kernel [strip][sample][stride]
     int max_strips = 0;
     long long x6w_off = -1;                    // floats: split weight pieces of the bf16x6 forward (conv_x6.hip), -1: shape not served
+    long long x6bw_off = -1;                   // floats: split weight pieces of the bf16x6 backward-data (conv_bwd_x6.hip), -1: shape not served
     mutable int family[3] = {0, 0, 0};         // kernel family of the last forward / backward-data / backward-weight launch (mfvi_plan_last_kernel)
 };
 
@@ -62,6 +63,7 @@ struct mfvi_plan {
     SampleEntry* samp_dev = nullptr; int n_samp = 0, samp_blocks = 0;    // layers whose weights are drawn once per pass
     long long wsamp_off = -1;                  // floats: sampled weights [max_samples][n_vi]
     X6SplitEntry* x6_dev = nullptr; std::vector<X6SplitEntry> x6_uploaded;      // table of the bf16x6 forward layers' weight split (conv_x6.hip)
+    X6BSplitEntry* x6b_dev = nullptr; std::vector<X6BSplitEntry> x6b_uploaded;   // the same for the bf16x6 backward-data layers (conv_bwd_x6.hip)
     int param_dtype = MFVI_PARAM_F32;          // storage of mu / rho handed to forward / backward (MFVI_PARAM_BF16: bf16_t arrays)
     int n_generic = 0;                         // conv layers outside the sampling table (served by the generic fp32 kernels)
     long long p32_off = -1;                    // floats: [mu | rho] expanded to float32 for those kernels when mu / rho are bf16
@@ -265,6 +267,8 @@ bool build(mfvi_plan& p, const mfvi_tensor_desc* td, int n_t, const mfvi_op_desc
             o.max_strips = (int)(ms < 1 ? 1 : (ms > 64 ? 64 : ms));
             o.part_off = take(o.part_stride * p.max_samples * o.max_strips);
             if (o.d.type == MFVI_OP_CONV) { const long long xf = x6_fwd_scratch_floats(o.g, p.max_samples); if (xf > 0) o.x6w_off = take(xf); }
+            if (o.d.type == MFVI_OP_CONV && o.d.in0 != p.input && p.t[o.d.in0].consumers.size() == 1) {      // (the fused-fold path: the conv's input feeds nothing else)
+                const long long xb = x6_bwd_scratch_floats(o.g, p.max_samples); if (xb > 0) o.x6bw_off = take(xb); }
         }
     p.total_bytes = p.float_base + fo * (long long)sizeof(float);
     if (n_conv) {
@@ -429,6 +433,7 @@ void mfvi_plan_destroy(mfvi_plan* plan)
     if (plan->table_dev) (void)hipFree(plan->table_dev);
     if (plan->fin_dev) (void)hipFree(plan->fin_dev);
     if (plan->x6_dev) (void)hipFree(plan->x6_dev);
+    if (plan->x6b_dev) (void)hipFree(plan->x6b_dev);
     if (plan->samp_dev) (void)hipFree(plan->samp_dev);
     if (plan->drop_dev) (void)hipFree(plan->drop_dev);
     for (auto e : plan->fork_events) (void)hipEventDestroy(e);
@@ -728,6 +733,29 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     // backward through a retained graph, a caller re-using a step index after an optimizer step) must re-draw from what mu / rho hold now
     plan->samp_n = 0;
     const float* wsrc = presample ? c.wsamp() : mu; const long long wstride = (presample && sample_weights) ? plan->n_vi : 0;
+    bool x6b_ready = false;
+    if (presample) {      // weight pieces of the layers whose backward-data runs on the bf16x6 kernel: one launch in front of the pass
+        std::vector<X6BSplitEntry> tab; int nb = 0;
+        for (auto& o : plan->ops)
+            if (o.d.type == MFVI_OP_CONV && o.x6bw_off >= 0 && (o.g.tune[1] & MFVI_TUNE_X6) && ((o.d.in0 != plan->input) || dz != nullptr)) {
+                X6BSplitEntry e; if (!x6b_split_entry(o.g, o.x6bw_off, &e)) continue;
+                e.first_block = nb; nb += (e.units + 255) / 256; tab.push_back(e);
+            }
+        if (!tab.empty()) {
+            hipError_t e = hipSuccess;
+            if (!plan->x6b_dev) e = hipMalloc((void**)&plan->x6b_dev, sizeof(X6BSplitEntry) * plan->ops.size());
+            const bool same = tab.size() == plan->x6b_uploaded.size() && memcmp(tab.data(), plan->x6b_uploaded.data(), sizeof(X6BSplitEntry) * tab.size()) == 0;
+            if (e == hipSuccess && !same) {
+                if (!plan->x6b_uploaded.empty()) (void)hipStreamSynchronize(st);      // a previous upload may still be reading the vector
+                plan->x6b_uploaded = tab;
+                e = hipMemcpyAsync(plan->x6b_dev, plan->x6b_uploaded.data(), sizeof(X6BSplitEntry) * tab.size(), hipMemcpyHostToDevice, st);
+            }
+            if (e != hipSuccess) { set_error("backward: weight-piece table setup failed: %s", hipGetErrorString(e)); return (int)e; }
+            const int rc = launch_x6b_split_all(plan->x6b_dev, (int)tab.size(), nb, c.wsamp(), sample_weights ? plan->n_vi : 0, sample_weights ? n_samples : 1, c.farena(), st);
+            if (rc) { set_error("backward: weight-piece launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+            x6b_ready = true;
+        }
+    }
     std::vector<GradFinEntry> fin; int fin_blocks = 0;      // layers whose dW went to partial slabs in this pass
     // side stream for the backward-weight kernels (MFVI_SIDE_STREAM=0: everything on the caller's stream)
     static const bool side_on = [] { const char* e = getenv("MFVI_SIDE_STREAM"); return !(e && e[0] == '0'); }();
@@ -887,7 +915,9 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                     ProfScope ps(plan, i, PASS_BWD_DATA, st);
                     { const int ra = arm(i); if (ra) return ra; }
                     mfvi_tl_family = 1;
+                    mfvi_tl_x6bw = (presample && o.x6bw_off >= 0) ? c.farena() + o.x6bw_off : nullptr; mfvi_tl_x6bw_ready = x6b_ready;
                     const int r2 = launch_conv_bwd_data_mfma(gy, o.g, wsrc, wstride, nullptr, 0, n_samples, st, &ff);
+                    mfvi_tl_x6bw = nullptr; mfvi_tl_x6bw_ready = false;
                     settle();
                     if (r2 == 0) o.family[1] = mfvi_tl_family;
                     if (r2 == 0) folded = true; else { armed_idx = -1; if (r2 != -2 && r2 != -3) rc = r2; }
@@ -1082,7 +1112,9 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                         // the fused-fold variant mfvi_backward will launch (it accumulates into the BN-backward sums: contents undefined afterwards)
                         FoldFuse ff; ff.x = xin; ff.ga = c.farena() + x.ga_off; ff.ga_sstride = x.numel;
                         ff.bsums = x.d.has_bn ? c.bsums() + x.stats_off : nullptr;
+                        mfvi_tl_x6bw = o.x6bw_off >= 0 ? c.farena() + o.x6bw_off : nullptr; mfvi_tl_x6bw_ready = false;      // (the launcher splits this layer's weights itself)
                         const int r2 = launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, nullptr, 0, n_samples, st, &ff);
+                        mfvi_tl_x6bw = nullptr;
                         if (r2 != -2) return r2;
                     }
                     return launch_conv_bwd_data_mfma(gy, o.g, c.wsamp(), plan->n_vi, c.farena() + o.scratch_off, per, n_samples, st);
@@ -1108,6 +1140,8 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                 if (which <= 1 && o.g.ks == 3 && o.g.stride == 1 && o.g.W <= 16) cands.push_back(1 | MFVI_TUNE_SM);
                 // bf16x6 forward (conv_x6.hip): output fragments per block, 8 output rows per block
                 if (which == 0 && o.x6w_off >= 0) for (int mf : {1, 2}) for (int T = 1; T <= 16; T *= 2) cands.push_back(mf | 8 << 8 | T << 16 | MFVI_TUNE_X6);
+                // bf16x6 backward-data with the fold (conv_bwd_x6.hip): strips per block; rows per strip follow the output-channel count
+                if (which == 1 && o.x6bw_off >= 0) for (int T : {1, 2, 4, 8, 16, 32}) cands.push_back(T | (o.g.Cout == 16 ? 8 : o.g.Cout == 32 ? 4 : 2) << 8 | MFVI_TUNE_X6);
             }
             else {
                 for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16);

@@ -234,9 +234,13 @@ def test_bench_tilings_against_reference_golden_256(M, golden_dir, name):
         _relerr(grs, g["drho_s_f64"]), _rel2(g["dmu_s"], g["dmu_s_f64"]), _relerr(g["dmu_s"], g["dmu_s_f64"])))
     # same reading as at 128^2 (test_gpu_parity.py): relative L2 tight, max-norm loose (LeakyReLU kink + train-mode BN); the fp32
     # reference's own distance to its float64 twin is printed above and bounds what "agreement" can mean (SR: 7e-3)
-    l2_tol = 2e-2 if task == "sr" else 2e-3
+    # Tolerances = about 3x what the HIP path measures (profiles/r04_parity_margins.txt: L2 2.7e-4 / 7.0e-3 / 2.0e-4, max-norm 2.5e-4 /
+    # 1.0e-2 / 1.8e-4 for den / sr / ct), never below ~2x the fp32 reference's own distance to its float64 twin (3.8e-4 / 6.8e-3 / 1.8e-4):
+    # the tilings are autotuned per box, and another summation order may flip a LeakyReLU kink the way the reference's own fp32 run does.
+    l2_tol = {"den": 1e-3, "sr": 2e-2, "ct": 8e-4}[task]
+    max_tol = {"den": 1e-3, "sr": 3e-2, "ct": 8e-4}[task]
     assert _rel2(gms, g["dmu_s_f64"]) < l2_tol and _rel2(grs, g["drho_s_f64"]) < l2_tol and _rel2(dbn.cpu().numpy(), g["dbn_f64"]) < 2 * l2_tol
-    assert _relerr(gms, g["dmu_s_f64"]) < 5e-2 and _relerr(grs, g["drho_s_f64"]) < 5e-2
+    assert _relerr(gms, g["dmu_s_f64"]) < max_tol and _relerr(grs, g["drho_s_f64"]) < max_tol
     ln = np.array([np.linalg.norm(dmu.cpu().numpy()[l["w_off"]:(l["b_off"] + l["cout"])]) for l in P.layers])
     assert _relerr(ln, g["dmu_layer_norm_f64"]) < 5 * l2_tol
     out_eval = plan.forward(d_mu, d_rho, d_bn, d_z, seed, 0, 0, n, sample_weights=False)

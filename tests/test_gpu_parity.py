@@ -226,9 +226,11 @@ def test_full_net_against_reference_golden(M, golden_dir, name, size):
         relerr(gms, g["dmu_s_f64"]), relerr(grs, g["drho_s_f64"]), relerr(host(dbn), g["dbn_f64"]), rel2(gms, g["dmu_s_f64"]),
         rel2(grs, g["drho_s_f64"]), relerr(g["dmu_s"], g["dmu_s_f64"]), rel2(g["dmu_s"], g["dmu_s_f64"])))
     # at 64x64 the deepest BatchNorm normalises over 2x2 pixels: the net is numerically degenerate there
-    l2_tol = 2e-2 if size == 64 else 2e-3
+    # measured (profiles/r04_parity_margins.txt): 128^2 L2 3.9e-5, max-norm 4.2e-5 (the fp32 reference itself: 4.8e-4 / 5.2e-4); 64^2 L2 4.9e-4,
+    # max-norm 5.0e-4.  Tolerance = 3x the measurement at 64^2, 2x the reference's own fp32 noise at 128^2 (one flipped kink costs that much)
+    l2_tol = 1.5e-3 if size == 64 else 1e-3
     assert rel2(gms, g["dmu_s_f64"]) < l2_tol and rel2(grs, g["drho_s_f64"]) < l2_tol and rel2(host(dbn), g["dbn_f64"]) < 2 * l2_tol
-    assert relerr(gms, g["dmu_s_f64"]) < 5e-2 and relerr(grs, g["drho_s_f64"]) < 5e-2
+    assert relerr(gms, g["dmu_s_f64"]) < l2_tol and relerr(grs, g["drho_s_f64"]) < l2_tol
     # RNG-free anchor
     out_eval = plan.forward(d_mu, d_rho, d_bn, d_z, seed, 0, 0, 1, sample_weights=False)
     assert relerr(host(out_eval)[0], g["out_eval"]) < 1e-4
