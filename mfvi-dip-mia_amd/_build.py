@@ -9,6 +9,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmfvi_hip.so")
 SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_bwd_x6.hip", "conv_small.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file extras.  conv_bwd_x6: no SLP vectorisation — packed fp32 instructions (v_pk_add / v_pk_fma) beside a matrix stream cost more issue time
+# than the scalar ones they replace (MI355X_MICROARCH.md; measured on this kernel: 68->32 @128^2 88.0 -> 78.8 us); the explicit pairs of the
+# bf16 split (common.h) stay packed
+FILE_FLAGS = {"conv_bwd_x6.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -35,7 +39,7 @@ def build(force=False, verbose=False):
 
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + os.environ.get("MFVI_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]     # e.g. -DPRODUCER_PRIO=1 for experiments
+        cmd = [cc] + FLAGS + FILE_FLAGS.get(src, []) + os.environ.get("MFVI_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]     # e.g. -DPRODUCER_PRIO=1 for experiments
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

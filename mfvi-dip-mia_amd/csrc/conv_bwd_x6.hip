@@ -52,8 +52,42 @@ __device__ __forceinline__ void split8(const float (&e)[8], u32x4& h, u32x4& m, 
     for (int i = 0; i < 4; ++i) { unsigned hh, mm, ll; split_pair_bf16x3(e[2 * i], e[2 * i + 1], hh, mm, ll); h[i] = hh; m[i] = mm; l[i] = ll; }
 }
 
-// BN-backward on load in three operations per element (as conv_rp.hip): dy = (y - mean) * qc + (ga * c1 + k2)
-struct BwdC { float mean, qc, c1, k2; };
+#ifndef X6B_PRIO_S
+#define X6B_PRIO_S 0
+#endif
+#ifndef X6B_PRIO_M
+#define X6B_PRIO_M 2
+#endif
+#ifdef X6B_PROF
+// dev build: per-phase s_memtime sums of matrix wave 0 / staging wave 0 of every block (scripts/dev/bwdx6_prof.py)
+__device__ unsigned long long g_x6b_prof[24];
+__device__ __forceinline__ unsigned long long xb_now() { unsigned long long t; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define XB_T(v) const unsigned long long v = xb_now()
+#define XB_ACC(slot, d) prof[slot] += (d)
+#else
+#define XB_T(v)
+#define XB_ACC(slot, d)
+#endif
+
+// Global accesses of the staging waves: wave-uniform base pointer + 32-bit BYTE offset per lane (the launcher keeps a sample's tensors
+// below 2^29 elements), so the compiler emits the scalar-base form and no per-lane 64-bit address lives in registers (with element
+// offsets it could not prove the scaling by 4 free of wrap-around and fell back to v_lshl_add_u64 per access: 16 spilled address registers)
+__device__ __forceinline__ float ldg_f(const float* base, unsigned boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff); }
+__device__ __forceinline__ float4 ldg_f4(const float* base, unsigned boff) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + boff); }
+__device__ __forceinline__ void stg_f4(float* base, unsigned boff, float4 v) { *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + boff) = v; }
+
+// sum over the 16 lanes of a DPP row, result in lane 15 of the row (lanes shifted in from outside the row read 0: bound_ctrl)
+__device__ __forceinline__ float row_sum16(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));      // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));      // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));      // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));      // row_shr:8
+    return v;
+}
+
+// BN-backward on load (conv_rp.hip's dy = (y - mean) * qc + (ga * c1 + k2) with the mean folded into the constant)
+struct BwdC { float qc, c1, k3, pad; };                   // dy = ga * c1 + (y * qc + k3), k3 = -c1 c2 - mean * qc: two operations per element
 
 template <bool K16, int SR, int NG>
 struct X6BCfg {
@@ -67,6 +101,8 @@ struct X6BCfg {
     static constexpr int NV = K16 ? 2 : 3;                  // weight operand variants per tap
     static constexpr int WB = 9 * NV * 1024;                // weight pieces of one pass
     static constexpr int NWU = (WB / 16 + 255) / 256;       // 16-byte units per staging thread
+    static constexpr int OPB = SR * 256 + 16;               // channel pitch of the finished tile [16][SR][64] floats; == 16 (mod 128 B): the 8 lanes of a ds_write_b128 group (8 channels) hit 32 distinct banks
+    static constexpr int SUMW = 1;                           // BN-backward sum slots per channel (the fold gives every channel ONE owner lane)
 };
 
 struct X6BArgs {
@@ -77,7 +113,7 @@ struct X6BArgs {
 };
 
 // ---- weight pieces: thread = (f, group, tap, n, k-octet) of sample k -> NV 16-byte operand units ----
-// destination (16-byte units): (((f * NG + grp) * 9 + tap) * NV + v) * 64 + n * 4 + g4
+// destination (16-byte units): (((f * NG + grp) * 9 + tap) * NV + v) * 64 + g4 * 16 + n
 __device__ __forceinline__ void x6b_split_body(const X6BSplitEntry& E, int u, int k, const float* w, long long wstride, float* arena)
 {
     if (u >= E.units) return;
@@ -89,7 +125,7 @@ __device__ __forceinline__ void x6b_split_body(const X6BSplitEntry& E, int u, in
     for (int j = 0; j < 8; ++j) e8[j] = ci < E.CI ? ww[((long long)(co0 + j) * E.CI + ci) * 9 + tap] : 0.f;
     u32x4 h, m, l; split8(e8, h, m, l);
     const int NV = E.k16 ? 2 : 3;
-    u32x4* d = reinterpret_cast<u32x4*>(arena + E.dst_off) + (long long)k * ((long long)E.units * NV) + ((long long)r * NV) * 64 + n * 4 + g4;
+    u32x4* d = reinterpret_cast<u32x4*>(arena + E.dst_off) + (long long)k * ((long long)E.units * NV) + ((long long)r * NV) * 64 + g4 * 16 + n;      // lane order (lane = 16 g4 + n): the wave's read of a unit is 1 KB of consecutive words, conflict-free
     if (E.k16) { d[0] = g4 < 2 ? h : m; d[64] = g4 < 2 ? l : h; }      // [w_h | w_m], [w_l | w_h]
     else { d[0] = h; d[64] = m; d[128] = l; }
 }
@@ -111,21 +147,26 @@ template <bool K16, int SR, int NG>
 __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
 {
     using C = X6BCfg<K16, SR, NG>;
-    constexpr int NOCT = C::NOCT, NOCTT = C::NOCTT, PLANE = C::PLANE, PIECE = C::PIECE, ROWB = C::ROWB, NR = C::NR, NV = C::NV;
-    extern __shared__ __align__(16) char lds[];             // ring [NR][3][NOCTT][80][16] | weight pieces [9][NV][16][4][16] | tables
+    constexpr int NOCTT = C::NOCTT, PLANE = C::PLANE, PIECE = C::PIECE, ROWB = C::ROWB, NR = C::NR, NV = C::NV, OPB = C::OPB, SUMW = C::SUMW;
+    extern __shared__ __align__(16) char lds[];             // ring [NR][3][NOCTT][80][16] | weight pieces [9][NV][64][16] | finished tile [16][OPB] | tables
     char* const s_w = lds + C::RING;
+    char* const s_out = s_w + C::WB;
     const ConvGeom& g = A.g;
     const int CI = g.Cin, CO = g.Cout, H = g.H, W = g.W, HW = H * W;
     const int NF = A.NF, NFS = NF * 16;
-    BwdC* const s_chb = reinterpret_cast<BwdC*>(s_w + C::WB);                       // [CO]
+    BwdC* const s_chb = reinterpret_cast<BwdC*>(s_out + 16 * OPB);                  // [CO]
     ChanFwd* const s_ch = reinterpret_cast<ChanFwd*>(s_chb + CO);                   // [NFS]
-    float* const s_sum = reinterpret_cast<float*>(s_ch + NFS);                      // [4][NFS][2]
+    float* const s_sum = reinterpret_cast<float*>(s_ch + NFS);                      // [SUMW][NFS][2]
 
     const int tid = threadIdx.x;
     const bool producer = tid >= 256;
     const int t = tid & 255, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
+#ifdef X6B_PROF
+    unsigned long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    XB_T(t_entry);
+#endif
     int bx, by, k;
     xcd_decode(blockIdx.x, A.nx, 1, A.nz, bx, by, k);
     const int band = bx % A.bands, strip0 = (bx / A.bands) * A.tpb;
@@ -136,11 +177,121 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
     const bool fuse_sums = A.fbsums != nullptr;
     const unsigned* __restrict__ wsp = A.wsp + (long long)k * A.wsp_stride_u4 * 4;
 
+    // ---- staging helpers (all eight waves stage the first window; afterwards only waves 4-7 use them) ----
+    const float* __restrict__ gsrc = A.gin.ga + (long long)k * A.gin.gstride;
+    const float* __restrict__ ysrc = A.gin.stats ? A.gin.y + (long long)k * A.gin.ystride : nullptr;
+    const bool lb = c0 == 0, rb = c0 + 64 == W;
+    // The SR new rows of a strip are 16 tasks (row j, octet q) of 64 pixels — SR * NOCTT == 16 for every instantiation — four per
+    // staging wave (task i of wave w: number w + 4 i), plus one task of the four special pixel slots of this wave's four (row, octet)
+    // pairs on lanes 0..15 (pair = lane >> 2, kind = lane & 3: left halo, right halo, left sum dy[2] + dy[0], right sum dy[W-3] + dy[W-1]).
+    static_assert(SR * NOCTT == 16, "task geometry");
+    const int pair = lane >> 2, kind = lane & 3;
+    u32x4 pc[5][3];                                     // finished pieces of the five tasks, waiting for the strip boundary
+    int jrow[5], qoct[5];                               // (task 4: per lane)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int tn = wv + 4 * i; jrow[i] = tn / NOCTT; qoct[i] = tn % NOCTT; }
+    { const int tn = wv + 4 * min(pair, 3); jrow[4] = tn / NOCTT; qoct[4] = tn % NOCTT; }
+    const bool sp_on = lane < 16 && (kind == 0 ? !lb : kind == 1 ? !rb : kind == 2 ? lb : rb);
+    const int colA = kind == 0 ? max(c0 - 1, 0) : kind == 1 ? min(c0 + 64, W - 1) : kind == 2 ? 2 : W - 3;
+    const int colB = kind == 2 ? 0 : W - 1;
+    const bool two = kind >= 2;
+    const int sslot = kind == 0 ? 0 : kind == 1 ? 65 : kind == 2 ? 66 : 67;
+    // (32-bit element offsets from a wave-uniform base: with 64-bit per-lane addresses the compiler kept ~100 address registers live)
+    const unsigned uHW = (unsigned)HW;
+    auto fetch_to = [&](int i, float (&ga)[8], float (&yy)[8], int Rb) {
+        const int R = min(max(Rb + jrow[i], 0), H - 1);
+        const unsigned off = 4u * ((unsigned)(8 * qoct[i]) * uHW + (unsigned)(R * W + c0) + (unsigned)lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ga[j] = ldg_f(gsrc, off + 4u * (unsigned)j * uHW); yy[j] = ysrc ? ldg_f(ysrc, off + 4u * (unsigned)j * uHW) : 0.f; }
+    };
+    auto fetch_sp_to = [&](float (&ga)[8], float (&ya)[8], float (&gb)[8], float (&yb)[8], int Rb) {
+        const int R = min(max(Rb + jrow[4], 0), H - 1);
+        const unsigned base = (unsigned)(8 * qoct[4]) * uHW + (unsigned)(R * W);
+        const unsigned oa = 4u * (base + (unsigned)colA), ob = 4u * (base + (unsigned)colB);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ga[j] = ldg_f(gsrc, oa + 4u * (unsigned)j * uHW); ya[j] = ysrc ? ldg_f(ysrc, oa + 4u * (unsigned)j * uHW) : 0.f;
+            gb[j] = ldg_f(gsrc, ob + 4u * (unsigned)j * uHW); yb[j] = ysrc ? ldg_f(ysrc, ob + 4u * (unsigned)j * uHW) : 0.f;
+        }
+    };
+    auto finish_from = [&](int i, const float (&ga)[8], const float (&yy)[8], int Rb) {
+        const int R = Rb + jrow[i];
+        float e[8];
+        int qi = __builtin_amdgcn_readfirstlane(8 * qoct[i]); asm volatile("" : "+s"(qi));      // opaque: the loop-invariant table reads are NOT hoisted over the strip loop
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const BwdC b = s_chb[qi + j]; e[j] = __builtin_fmaf(ga[j], b.c1, __builtin_fmaf(yy[j], b.qc, b.k3)); }
+        if (R < 0 || R >= H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = 0.f;
+        }
+        split8(e, pc[i][0], pc[i][1], pc[i][2]);
+    };
+    auto finish_sp_from = [&](const float (&ga)[8], const float (&ya)[8], const float (&gb)[8], const float (&yb)[8], int Rb) {
+        const int R = Rb + jrow[4];
+        float e[8];
+        int qi = 8 * qoct[4]; asm volatile("" : "+v"(qi));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const BwdC b = s_chb[qi + j];
+            const float a = __builtin_fmaf(ga[j], b.c1, __builtin_fmaf(ya[j], b.qc, b.k3));
+            const float c = __builtin_fmaf(gb[j], b.c1, __builtin_fmaf(yb[j], b.qc, b.k3));
+            e[j] = two ? a + c : a;
+        }
+        if (!sp_on || R < 0 || R >= H) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = 0.f;
+        }
+        split8(e, pc[4][0], pc[4][1], pc[4][2]);
+    };
+    // write the five tasks' pieces into the ring rows of image rows Rb .. Rb + nvalid - 1 (ring slot of image row R: (R + 1) mod NR)
+    auto write = [&](int Rb, int nvalid) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (jrow[i] >= nvalid) continue;
+            if (i == 4 && lane >= 16) continue;
+            const int slot = (Rb + jrow[i] + 1 + NR) % NR;
+            char* d = lds + slot * ROWB + qoct[i] * PLANE + (i == 4 ? sslot : 1 + lane) * 16;
+            *reinterpret_cast<u32x4*>(d) = pc[i][0]; *reinterpret_cast<u32x4*>(d + PIECE) = pc[i][1]; *reinterpret_cast<u32x4*>(d + 2 * PIECE) = pc[i][2];
+        }
+    };
+    // weight pieces of pass p (fragment p / NG % NF, group p % NG): WB contiguous bytes
+    u32x4 wq[C::NWU];
+    auto wfetch = [&](int p) {
+        const int fg = p % n_pps;
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(wsp) + (long long)fg * (C::WB / 16);
+#pragma unroll
+        for (int j = 0; j < C::NWU; ++j) wq[j] = src[min(t + 256 * j, C::WB / 16 - 1)];
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < C::NWU; ++j) if (t + 256 * j < C::WB / 16) *reinterpret_cast<u32x4*>(s_w + (t + 256 * j) * 16) = wq[j];
+    };
+
+    // Prologue, part 1: the first strip's window (image rows r0 - 1 .. r0 + SR) is staged by ALL eight waves — waves 4-7 its first SR
+    // rows, waves 0-3 the last two — and every global load of it is issued before anything waits, the channel tables included: one
+    // memory round trip (first version: seven, 26 k cycles per block).
+    const int pro_rd = producer ? 0 : 1;
+    const int pro_Rb = strip0 * SR - 1 + pro_rd * SR, pro_nvalid = pro_rd == 0 ? SR : 2;
+    float pg[6][8], py[6][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (pro_rd == 0 || jrow[i] < 2) fetch_to(i, pg[i], py[i], pro_Rb);
+    fetch_sp_to(pg[4], py[4], pg[5], py[5], pro_Rb);
+    if (producer) wfetch(0);
+
     if (!producer) {
-        for (int c = t; c < CO; c += 256) { const ChanBwd b = chan_bwd(A.gin, k, c); BwdC r; r.mean = b.mean; r.qc = -b.c1 * b.c3 * b.rstd; r.c1 = b.c1; r.k2 = -b.c1 * b.c2; s_chb[c] = r; }
+        for (int c = t; c < CO; c += 256) { const ChanBwd b = chan_bwd(A.gin, k, c); BwdC r; r.qc = -b.c1 * b.c3 * b.rstd; r.c1 = b.c1; r.k3 = __builtin_fmaf(-b.mean, r.qc, -b.c1 * b.c2); r.pad = 0.f; s_chb[c] = r; }
         for (int c = t; c < NFS; c += 256) { ChanFwd f; if (fuse_sums) f = chan_fwd(A.xin, k, min(c, CI - 1)); else { f.mean = 0.f; f.scale = 1.f; f.beta = 0.f; f.rstd = 1.f; } s_ch[c] = f; }
-        for (int i = t; i < 4 * NFS * 2; i += 256) s_sum[i] = 0.f;
+        for (int i = t; i < SUMW * NFS * 2; i += 256) s_sum[i] = 0.f;
     }
+
+    XB_T(sp0); XB_ACC(19, sp0 - t_entry);                                       // prologue: loads issued, tables built
+    __syncthreads();                                        // (S0) channel tables visible
+    XB_T(sp1); XB_ACC(20, sp1 - sp0);                                           // prologue: wait at S0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (pro_rd == 0 || jrow[i] < 2) finish_from(i, pg[i], py[i], pro_Rb);
+    finish_sp_from(pg[4], py[4], pg[5], py[5], pro_Rb);
+    write(pro_Rb, pro_nvalid);
+    XB_T(sp2); XB_ACC(21, sp2 - sp1);                                           // prologue: transform + split + write
 
 #ifdef X6B_DBG_NOPROD
     if (false) {
@@ -148,139 +299,166 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
     if (producer) {
 #endif
         // ======================= staging waves =======================
-        __builtin_amdgcn_s_setprio(1);
-        const float* __restrict__ gsrc = A.gin.ga + (long long)k * A.gin.gstride;
-        const float* __restrict__ ysrc = A.gin.stats ? A.gin.y + (long long)k * A.gin.ystride : nullptr;
-        const bool lb = c0 == 0, rb = c0 + 64 == W;
-        // The SR new rows of a strip are 16 tasks (row j, octet q) of 64 pixels — SR * NOCTT == 16 for every instantiation — four per
-        // staging wave (task i of wave w: number w + 4 i), plus one task of the four special pixel slots of this wave's four (row, octet)
-        // pairs on lanes 0..15 (pair = lane >> 2, kind = lane & 3: left halo, right halo, left sum dy[2] + dy[0], right sum dy[W-3] + dy[W-1]).
-        static_assert(SR * NOCTT == 16, "task geometry");
-        const int pair = lane >> 2, kind = lane & 3;
-        u32x4 pc[5][3];                                     // finished pieces of the five tasks, waiting for the strip boundary
-        float ga_[2][8], y_[2][8];                          // raw loads of two tasks in flight (the special-slot task uses both sets: column A, column B)
-        int jrow[5], qoct[5];                               // (task 4: per lane)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int tn = wv + 4 * i; jrow[i] = tn / NOCTT; qoct[i] = tn % NOCTT; }
-        { const int tn = wv + 4 * min(pair, 3); jrow[4] = tn / NOCTT; qoct[4] = tn % NOCTT; }
-        const bool sp_on = lane < 16 && (kind == 0 ? !lb : kind == 1 ? !rb : kind == 2 ? lb : rb);
-        const int colA = kind == 0 ? max(c0 - 1, 0) : kind == 1 ? min(c0 + 64, W - 1) : kind == 2 ? 2 : W - 3;
-        const int colB = kind == 2 ? 0 : W - 1;
-        const bool two = kind >= 2;
-        const int sslot = kind == 0 ? 0 : kind == 1 ? 65 : kind == 2 ? 66 : 67;
-        // fetch: raw ga / y of task i for the rows starting at image row Rb (rows outside the image: clamped, zeroed in finish)
-        // (32-bit element offsets from a wave-uniform base: with 64-bit per-lane addresses the compiler kept ~100 address registers live)
-        const unsigned uHW = (unsigned)HW;
-        auto fetch = [&](int i, int set, int Rb) {
-            const int R = min(max(Rb + jrow[i], 0), H - 1);
-            const unsigned off = (unsigned)(8 * qoct[i]) * uHW + (unsigned)(R * W + c0) + (unsigned)lane;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { ga_[set][j] = gsrc[off + (unsigned)j * uHW]; y_[set][j] = ysrc ? ysrc[off + (unsigned)j * uHW] : 0.f; }
-        };
-        auto fetch_sp = [&](int Rb) {
-            const int R = min(max(Rb + jrow[4], 0), H - 1);
-            const unsigned base = (unsigned)(8 * qoct[4]) * uHW + (unsigned)(R * W);
-            const unsigned oa = base + (unsigned)colA, ob = base + (unsigned)colB;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                ga_[0][j] = gsrc[oa + (unsigned)j * uHW]; y_[0][j] = ysrc ? ysrc[oa + (unsigned)j * uHW] : 0.f;
-                ga_[1][j] = gsrc[ob + (unsigned)j * uHW]; y_[1][j] = ysrc ? ysrc[ob + (unsigned)j * uHW] : 0.f;
+        __builtin_amdgcn_s_setprio(X6B_PRIO_S);
+        // The staging of the next strip's SR rows rides on the strip's passes in PHASES: a phase first consumes (BN-backward, split) what the
+        // phase before requested, then requests its own loads.  Four phases on two raw register sets; the 16-output-channel layers have only
+        // three passes per strip (three input-channel fragments), so they run three phases on three sets (a consume right behind its own
+        // request would expose a memory round trip every strip).
+        constexpr int NSET = K16 ? 3 : 2, NPH = K16 ? 3 : 4;
+        float ga_[NSET][8], y_[NSET][8];
+        auto phase_consume = [&](int ph, int Rb) {
+            Rb = __builtin_amdgcn_readfirstlane(Rb); asm volatile("" : "+s"(Rb));      // opaque: per-load offsets are recomputed where they are used, not hoisted out of the pass loop (~100 registers)
+            if constexpr (K16) {
+                if (ph == 1) { finish_from(0, ga_[0], y_[0], Rb); finish_from(1, ga_[1], y_[1], Rb); finish_from(2, ga_[2], y_[2], Rb); }
+                else if (ph == 2) { finish_from(3, ga_[0], y_[0], Rb); finish_sp_from(ga_[1], y_[1], ga_[2], y_[2], Rb); }
+            } else {
+                if (ph == 1) { finish_from(0, ga_[0], y_[0], Rb); finish_from(1, ga_[1], y_[1], Rb); }
+                else if (ph == 2) { finish_from(2, ga_[0], y_[0], Rb); finish_from(3, ga_[1], y_[1], Rb); }
+                else if (ph == 3) finish_sp_from(ga_[0], y_[0], ga_[1], y_[1], Rb);
             }
         };
-        auto finish = [&](int i, int set, int Rb) {
-            const int R = Rb + jrow[i];
-            float e[8];
-            int qi = __builtin_amdgcn_readfirstlane(8 * qoct[i]); asm volatile("" : "+s"(qi));      // opaque: the loop-invariant table reads are NOT hoisted over the strip loop (160 registers)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const BwdC b = s_chb[qi + j]; e[j] = __builtin_fmaf(y_[set][j] - b.mean, b.qc, __builtin_fmaf(ga_[set][j], b.c1, b.k2)); }
-            if (R < 0 || R >= H) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = 0.f;
-            }
-            split8(e, pc[i][0], pc[i][1], pc[i][2]);
-        };
-        auto finish_sp = [&](int Rb) {
-            const int R = Rb + jrow[4];
-            float e[8];
-            int qi = 8 * qoct[4]; asm volatile("" : "+v"(qi));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const BwdC b = s_chb[qi + j];
-                const float a = __builtin_fmaf(y_[0][j] - b.mean, b.qc, __builtin_fmaf(ga_[0][j], b.c1, b.k2));
-                const float c = __builtin_fmaf(y_[1][j] - b.mean, b.qc, __builtin_fmaf(ga_[1][j], b.c1, b.k2));
-                e[j] = two ? a + c : a;
-            }
-            if (!sp_on || R < 0 || R >= H) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = 0.f;
-            }
-            split8(e, pc[4][0], pc[4][1], pc[4][2]);
-        };
-        // the staging of SR rows in four phases (loads of a phase are consumed by the next one)
-        auto phase = [&](int ph, int Rb) {
-            Rb = __builtin_amdgcn_readfirstlane(Rb); asm volatile("" : "+s"(Rb));      // opaque: the per-load offsets are recomputed where they are used, not hoisted out of the pass loop (they are invariant there: ~100 registers)
-            if (ph == 0) { fetch(0, 0, Rb); fetch(1, 1, Rb); }
-            else if (ph == 1) { finish(0, 0, Rb); finish(1, 1, Rb); fetch(2, 0, Rb); fetch(3, 1, Rb); }
-            else if (ph == 2) { finish(2, 0, Rb); finish(3, 1, Rb); fetch_sp(Rb); }
-            else finish_sp(Rb);
-        };
-        // write the five tasks' pieces into the ring rows of image rows Rb .. Rb + nvalid - 1 (ring slot of image row R: (R + 1) mod NR)
-        auto write = [&](int Rb, int nvalid) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                if (jrow[i] >= nvalid) continue;
-                if (i == 4 && lane >= 16) continue;
-                const int slot = (Rb + jrow[i] + 1 + NR) % NR;
-                char* d = lds + slot * ROWB + qoct[i] * PLANE + (i == 4 ? sslot : 1 + lane) * 16;
-                *reinterpret_cast<u32x4*>(d) = pc[i][0]; *reinterpret_cast<u32x4*>(d + PIECE) = pc[i][1]; *reinterpret_cast<u32x4*>(d + 2 * PIECE) = pc[i][2];
+        auto phase_request = [&](int ph, int Rb) {
+            Rb = __builtin_amdgcn_readfirstlane(Rb); asm volatile("" : "+s"(Rb));
+            if constexpr (K16) {
+                if (ph == 0) { fetch_to(0, ga_[0], y_[0], Rb); fetch_to(1, ga_[1], y_[1], Rb); fetch_to(2, ga_[2], y_[2], Rb); }
+                else if (ph == 1) { fetch_to(3, ga_[0], y_[0], Rb); fetch_sp_to(ga_[1], y_[1], ga_[2], y_[2], Rb); }
+            } else {
+                if (ph == 0) { fetch_to(0, ga_[0], y_[0], Rb); fetch_to(1, ga_[1], y_[1], Rb); }
+                else if (ph == 1) { fetch_to(2, ga_[0], y_[0], Rb); fetch_to(3, ga_[1], y_[1], Rb); }
+                else if (ph == 2) fetch_sp_to(ga_[0], y_[0], ga_[1], y_[1], Rb);
             }
         };
-        // weight pieces of pass p (fragment p / NG % NF, group p % NG): WB contiguous bytes
-        u32x4 wq[C::NWU];
-        auto wfetch = [&](int p) {
-            const int fg = p % n_pps;
-            const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(wsp) + (long long)fg * (C::WB / 16);
+        // ---- the fold of a finished tile (fragment f of the strip at image row r0), dumped into s_out by the matrix waves at the head of the
+        //      pass after the one that finished it.  Thread t owns channel t >> 4 of the fragment and float4 column t & 15 of every tile row:
+        //      16 lanes = one 256-byte row of one channel in every global access, and a thread's SR items share their channel — its two
+        //      BN-backward sums stay in registers over the tile and cost ONE 16-lane DPP reduction per pass (first version: a wave-wide
+        //      ds_bpermute reduction per item, 13 k cycles per pass).
+        constexpr int NIT = SR;                             // items (tile rows) per thread
+        float4 xpre[NIT];                                   // raw x of the pending fold, requested one pass ahead
+        const bool xact = (A.xin.act & 1) != 0; const float xslope = A.xin.slope;
+        const float* __restrict__ xq = fuse_sums ? A.xin.data + (long long)k * A.xin.sstride : nullptr;
+        float* __restrict__ gout = A.fga + (long long)k * A.fga_sstride;
+        const int fchl = t >> 4, fv = t & 15;
+        auto xprefetch = [&](int r0, int f) {
+#ifdef X6B_DBG_NOFOLDLD
+            return;
+#endif
+            if (!fuse_sums) return;
+            r0 = __builtin_amdgcn_readfirstlane(r0); asm volatile("" : "+s"(r0));
+            const int ch = 16 * f + fchl;
+            const unsigned off = 4u * ((unsigned)ch * uHW + (unsigned)(r0 * W + c0 + 4 * fv));
 #pragma unroll
-            for (int j = 0; j < C::NWU; ++j) wq[j] = src[min(t + 256 * j, C::WB / 16 - 1)];
+            for (int j = 0; j < NIT; ++j) xpre[j] = ch < CI ? ldg_f4(xq, off + 4u * (unsigned)(j * W)) : make_float4(0.f, 0.f, 0.f, 0.f);
         };
-        auto wstore = [&]() {
+        auto fold_t = [&](int r0, int f, auto sums_c, auto act_c) {       // straight-line per variant: no per-item branches in the staging waves' stream
+            constexpr bool SUMS = decltype(sums_c)::value, ACT = decltype(act_c)::value;
+            r0 = __builtin_amdgcn_readfirstlane(r0); asm volatile("" : "+s"(r0));
+            const int ch = 16 * f + fchl;
+            const unsigned off = 4u * ((unsigned)ch * uHW + (unsigned)(r0 * W + c0 + 4 * fv));
+            const char* so = s_out + fchl * OPB + fv * 16;
+            const ChanFwd cf = s_ch[ch];
+            float fs = 0.f, fx = 0.f;
+            constexpr int CH = NIT < 4 ? NIT : 4;           // items in flight (registers: NIT = 8 tile rows at once spilled)
 #pragma unroll
-            for (int j = 0; j < C::NWU; ++j) if (t + 256 * j < C::WB / 16) *reinterpret_cast<u32x4*>(s_w + (t + 256 * j) * 16) = wq[j];
+            for (int j0 = 0; j0 < NIT; j0 += CH) {
+                float4 d4[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) d4[j] = *reinterpret_cast<const float4*>(so + (j0 + j) * 256);
+#pragma unroll
+                for (int jj = 0; jj < CH; ++jj) {
+                    const int j = j0 + jj;
+                    float dd[4] = {d4[jj].x, d4[jj].y, d4[jj].z, d4[jj].w};
+                    if constexpr (SUMS) {
+                        const float yy[4] = {xpre[j].x, xpre[j].y, xpre[j].z, xpre[j].w};
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) {
+                            const float ym = yy[l] - cf.mean;
+                            if constexpr (ACT) { const float vv = __builtin_fmaf(ym, cf.scale, cf.beta); dd[l] *= (vv > 0.f) ? 1.f : xslope; }
+                            fs += dd[l]; fx = __builtin_fmaf(dd[l], ym, fx);      // (views without an activation — the concat tensors of the skip() nets — three operations per element)
+                        }
+                    }
+#ifdef X6B_DBG_NOFOLDST
+                    if (ch < CI && dd[0] == 1.2345f)
+#else
+                    if (ch < CI)
+#endif
+                        stg_f4(gout, off + 4u * (unsigned)(j * W), make_float4(dd[0], dd[1], dd[2], dd[3]));
+                }
+            }
+            XB_T(f3);
+            if constexpr (SUMS) {
+                // sums over the channel's 16 lanes on the DPP path (v += row_shr(v) by 1, 2, 4, 8: the total lands in lane 15 of the row)
+                fs = row_sum16(fs); fx = row_sum16(fx);
+                if (fv == 15 && ch < CI) { float* sp = s_sum + ch * 2; sp[0] += fs; sp[1] += fx; }      // one owner per channel: no atomics
+            }
+#ifdef X6B_PROF
+            XB_T(f4); XB_ACC(11, f4 - f3);                                      // fold: reduction + sum slots
+#endif
+        };
+        auto fold = [&](int r0, int f) {
+            if (!fuse_sums) fold_t(r0, f, std::false_type{}, std::false_type{});
+            else if (xact) fold_t(r0, f, std::true_type{}, std::true_type{});
+            else fold_t(r0, f, std::true_type{}, std::false_type{});
         };
 
-        wfetch(0);
-        __syncthreads();                                    // (S0) channel tables visible
-        // prologue: the first strip's window, rows r0 - 1 .. r0 + SR, in two rounds of SR rows
-        const int r00 = strip0 * SR;
-#pragma unroll 1
-        for (int rbase = 0; rbase < SR + 2; rbase += SR) {
-            const int Rb = r00 - 1 + rbase, nvalid = min(SR, SR + 2 - rbase);
-            phase(0, Rb); phase(1, Rb); phase(2, Rb); phase(3, Rb);
-            write(Rb, nvalid);
-        }
         wstore();
+        XB_T(s_pro); XB_ACC(12, s_pro - t_entry);
         lds_barrier();                                      // (B1) window of strip 0 and W(0) published
         int p = 0;
+        bool pend = false; int pend_r0 = 0, pend_f = 0;     // a finished tile waits in the matrix waves' registers / s_out
 #pragma unroll 1
         for (int ts = 0; ts < n_strip; ++ts) {
             const bool more = ts + 1 < n_strip;
-            const int Rb = (strip0 + ts + 1) * SR + 1;      // first NEW image row of the next strip's window
+            const int r0 = (strip0 + ts) * SR;
+            const int Rb = r0 + SR + 1;                     // first NEW image row of the next strip's window
 #pragma unroll 1
             for (int ps = 0; ps < n_pps; ++ps, ++p) {
                 const bool wnext = p + 1 < n_pass;
+                XB_T(s0);
+#ifndef X6B_DBG_NOWCOPY
                 if (wnext) wfetch(p + 1);
-                lds_barrier();                              // (B2) the matrix waves hold W(p) in registers
+#endif
+                lds_barrier();                              // (B2) the matrix waves hold W(p) in registers; a pending tile is in s_out
+                XB_T(s1); XB_ACC(13, s1 - s0);                                  // wait at B2
+#ifndef X6B_DBG_NOWCOPY
                 if (wnext) wstore();
-                if (more) {
-                    // phase ph of the next strip's staging rides on pass min(ph, n_pps - 1) of this strip
-                    const bool lastp = ps == n_pps - 1;
+#endif
+                XB_T(s2); XB_ACC(14, s2 - s1);                                  // weight copy (waits for its loads)
+                // Order inside a pass: everything that CONSUMES loads of the pass before (the fold: raw x; the phase: dy rows), then
+                // everything that REQUESTS (raw x of the tile this pass finishes, the phase's next rows) — vmcnt retires in order, so a
+                // consumer behind a fresh request would wait for that request as well
+                if (pend) { fold(pend_r0, pend_f); pend = false; }
+                XB_T(s2b); XB_ACC(18, s2b - s2);                                // fold of the previous tile
+#ifndef X6B_DBG_NOSTAGE
+                if (more) {      // phase ps of the next strip's staging rides on pass ps of this strip
 #pragma unroll
-                    for (int ph = 0; ph < 4; ++ph) if (ph == ps || (lastp && ph > ps)) phase(ph, Rb);
+                    for (int ph = 1; ph < NPH; ++ph) if (ph == ps) phase_consume(ph, Rb);
                 }
+#endif
+                if (ps % NG == NG - 1) { pend = true; pend_r0 = r0; pend_f = ps / NG; xprefetch(r0, pend_f); }      // this pass finishes fragment ps / NG
+#ifndef X6B_DBG_NOSTAGE
+                if (more) {
+#pragma unroll
+                    for (int ph = 0; ph < NPH - 1; ++ph) if (ph == ps) phase_request(ph, Rb);
+                    if (ps == n_pps - 1) {      // a strip with fewer passes than phases: the rest one after the other (each consume waits for its own request)
+#pragma unroll
+                        for (int ph = 1; ph < NPH; ++ph) if (ph > ps) { phase_consume(ph, Rb); if (ph < NPH - 1) phase_request(ph, Rb); }
+                    }
+                }
+#endif
+                XB_T(s3); XB_ACC(15, s3 - s2b);                                 // staging phase of this pass
                 lds_barrier();                              // (B1) W(p + 1) published; the matrix waves are done with pass p
+                XB_T(s4); XB_ACC(16, s4 - s3);                                  // wait at B1
             }
+            XB_T(s5);
             if (more) { write(Rb, SR); lds_barrier(); }     // (B3) next strip's window published
+            XB_T(s6); XB_ACC(17, s6 - s5);
         }
+        lds_barrier();                                      // (BF) the last tile is in s_out
+        if (pend) fold(pend_r0, pend_f);
+#ifdef X6B_PROF
+        if (t == 0) { for (int i = 12; i < 24; ++i) atomicAdd(&g_x6b_prof[i], prof[i]); atomicAdd(&g_x6b_prof[10], prof[10]); atomicAdd(&g_x6b_prof[11], prof[11]); }
+#endif
         if (fuse_sums) __syncthreads();                     // (Z)
 #ifdef X6B_DBG_NOMAT
     } else if (false) {
@@ -288,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
     } else {
 #endif
         // ======================= matrix waves: wave = 16-pixel fragment =======================
+        __builtin_amdgcn_s_setprio(X6B_PRIO_M);
         const int pf = wv;
         const bool lb = c0 == 0, rbd = c0 + 64 == W;
         int ax[3], axl[3];                                  // byte offsets of this lane's pixel operand inside a ring row, per kx
@@ -299,13 +478,16 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
             ax[kx] = (K16 ? (l4 & 1) : l4) * PLANE + sl * 16;
             axl[kx] = ax[kx] + (l4 >= 2 ? 2 * PIECE : 0);   // K16: [x_h | x_l]
         }
-        const char* const swl = s_w + (l15 * 4 + l4) * 16;
-        const int x0 = c0 + 16 * pf + 4 * l4;
-        const bool xact = (A.xin.act & 1) != 0; const float xslope = A.xin.slope;
-        const float* __restrict__ xq = fuse_sums ? A.xin.data + (long long)k * A.xin.sstride : nullptr;
-        float* __restrict__ gout = A.fga + (long long)k * A.fga_sstride;
-        __syncthreads();                                    // (S0)
+        const char* const swl = s_w + lane * 16;            // ((l15 * 4 + l4) * 16, conv_x6.hip's order, is a 2-way bank conflict: lanes l15 and l15 + 4 share banks)
+        char* const so = s_out + l15 * OPB + (16 * pf + 4 * l4) * 4;      // register r of acc[o] = pixel 16 pf + 4 l4 + r of channel l15, tile row o
+        f32x4 acc[SR];
+        bool dump = false;
+        auto dump_tile = [&]() {
+#pragma unroll
+            for (int o = 0; o < SR; ++o) *reinterpret_cast<f32x4*>(so + o * 256) = acc[o];
+        };
         lds_barrier();                                      // (B1)
+        XB_T(m_pro); XB_ACC(0, m_pro - t_entry);
 #pragma unroll 1
         for (int ts = 0; ts < n_strip; ++ts) {
             const int r0 = (strip0 + ts) * SR;
@@ -316,31 +498,33 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
               for (int ii = 0; ii < SR + 2; ++ii) { int s = b0 + ii; s = s >= NR ? s - NR : s; ro[ii] = s * ROWB; } }
 #pragma unroll 1
             for (int f = 0; f < NF; ++f) {
-                f32x4 acc[SR];
-                float4 xf[SR];
-                const int ch = 16 * f + l15;
-                const bool chv = ch < CI;
 #pragma unroll 1
                 for (int grp = 0; grp < NG; ++grp) {
+                    XB_T(m0);
+                    if (dump) { dump_tile(); dump = false; }      // the tile finished by the previous pass: the staging waves fold it during this pass
                     u32x4 Wr[9][NV];
 #pragma unroll
                     for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
                         for (int v = 0; v < NV; ++v) Wr[tp][v] = *reinterpret_cast<const u32x4*>(swl + (tp * NV + v) * 1024);
-                    lds_barrier();                          // (B2) W in registers
+#ifdef X6B_PROF
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    XB_T(m1); XB_ACC(1, m1 - m0);                               // tile dump + weight reads
+                    lds_barrier();                          // (B2) W in registers, tile in s_out
+                    XB_T(m2); XB_ACC(2, m2 - m1);                               // wait at B2
                     if (grp == 0) {
 #pragma unroll
                         for (int o = 0; o < SR; ++o) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (fuse_sums) {
-#pragma unroll
-                            for (int o = 0; o < SR; ++o) xf[o] = chv ? *reinterpret_cast<const float4*>(xq + (long long)ch * HW + (r0 + o) * W + x0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
                     }
                     const int goff = grp * 4 * PLANE;
                     constexpr int NGRP = (SR + 2) * 3;
                     u32x4 X[2][3];
                     auto issue = [&](int gi, u32x4 (&x)[3]) {
                         const int ii = gi / 3, kx = gi - 3 * ii;
+#ifdef X6B_DBG_NOXREAD
+                        if (ii >= 0) { x[0] = (u32x4){1u, 2u, 3u, (unsigned)gi}; x[1] = x[0]; x[2] = x[0]; return; }
+#endif
                         if constexpr (K16) {
                             const char* p = lds + ro[ii] + ax[kx];
                             x[0] = *reinterpret_cast<const u32x4*>(p);                           // [x_h | x_h]
@@ -352,15 +536,10 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
                             for (int pc = 0; pc < 3; ++pc) x[pc] = *reinterpret_cast<const u32x4*>(p + pc * PIECE);
                         }
                     };
-                    auto mm = [&](int o, const u32x4 (&x)[3], const u32x4 (&w)[NV]) {
-                        f32x4 a = acc[o];
-                        if constexpr (K16) { a = mfma_bf(x[2], w[1], a); a = mfma_bf(x[1], w[0], a); a = mfma_bf(x[0], w[0], a); }
-                        else {      // pieces (x, w): (l,h), (h,l), (m,m), (m,h), (h,m), (h,h) — small terms first
-                            a = mfma_bf(x[2], w[0], a); a = mfma_bf(x[0], w[2], a); a = mfma_bf(x[1], w[1], a);
-                            a = mfma_bf(x[1], w[0], a); a = mfma_bf(x[0], w[1], a); a = mfma_bf(x[0], w[0], a);
-                        }
-                        acc[o] = a;
-                    };
+                    // products of one (x, w) operand pair of a tap, small terms first: K16 ([x_h|x_l].[w_l|w_h], [x_m|x_m].[w_h|w_m], [x_h|x_h].[w_h|w_m]);
+                    // otherwise pieces (x, w): (l,h), (h,l), (m,m), (m,h), (h,m), (h,h)
+                    constexpr int NQ = K16 ? 3 : 6;
+                    constexpr int QX[6] = {2, K16 ? 1 : 0, K16 ? 0 : 1, 1, 0, 0}, QW[6] = {K16 ? 1 : 0, K16 ? 0 : 2, K16 ? 0 : 1, 0, 1, 0};
                     issue(0, X[0]);
 #pragma unroll
                     for (int gi = 0; gi < NGRP; ++gi) {
@@ -368,51 +547,53 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6_kernel(X6BArgs A)
                         __builtin_amdgcn_sched_barrier(0);
                         if (gi + 1 < NGRP) issue(gi + 1, X[(gi + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
-                        // image row r0 - 1 + ii meets output row o = ii + ky - 2 through tap row ky
+                        const u32x4 (&x)[3] = X[gi & 1];
+#ifdef X6B_DBG_NOMFMA
+                        if (ii >= 0) continue;
+#endif
+                        // image row r0 - 1 + ii meets output row o = ii + ky - 2 through tap row ky; the product loop is OUTSIDE the tap-row loop so
+                        // that consecutive matrix instructions accumulate into different rows' registers
 #pragma unroll
-                        for (int ky = 0; ky < 3; ++ky) {
-                            const int o = ii + ky - 2;
-                            if (o >= 0 && o < SR) mm(o, X[gi & 1], Wr[ky * 3 + kx]);
-                            else if (ii == 1 && ky == 0) { if (first) mm(1, X[gi & 1], Wr[ky * 3 + kx]); }                 // image row 0 -> padded row -1 -> row 1
-                            else if (ii == SR && ky == 2) { if (last) mm(SR - 2, X[gi & 1], Wr[ky * 3 + kx]); }            // image row H-1 -> padded row H -> row H-2
+                        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const int o = ii + ky - 2;
+                                if (o >= 0 && o < SR) acc[o] = mfma_bf(x[QX[q]], Wr[ky * 3 + kx][QW[q]], acc[o]);
+                            }
+                        if (ii == 1 && first) {             // image row 0 -> padded row -1 -> row 1 (tap row 0)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[1] = mfma_bf(x[QX[q]], Wr[kx][QW[q]], acc[1]);
+                        }
+                        if (ii == SR && last) {             // image row H-1 -> padded row H -> row H-2 (tap row 2)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[SR - 2] = mfma_bf(x[QX[q]], Wr[6 + kx][QW[q]], acc[SR - 2]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (grp == NG - 1) {
-                        // ---- fold: register r of acc[o] = pixel x0 + r of channel ch, image row r0 + o ----
-                        const ChanFwd cf = s_ch[ch];
-                        float fs = 0.f, fx = 0.f;
-#pragma unroll
-                        for (int o = 0; o < SR; ++o) {
-                            float dd[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
-                            if (fuse_sums) {
-                                const float yy[4] = {xf[o].x, xf[o].y, xf[o].z, xf[o].w};
-#pragma unroll
-                                for (int l = 0; l < 4; ++l) {
-                                    const float ym = yy[l] - cf.mean;
-                                    if (xact) { const float vv = __builtin_fmaf(ym, cf.scale, cf.beta); dd[l] *= (vv > 0.f) ? 1.f : xslope; }
-                                    fs += dd[l]; fx = __builtin_fmaf(dd[l], ym, fx);
-                                }
-                            }
-                            if (chv) *reinterpret_cast<float4*>(gout + (long long)ch * HW + (r0 + o) * W + x0) = make_float4(dd[0], dd[1], dd[2], dd[3]);
-                        }
-                        if (fuse_sums) {
-                            fs += __shfl_xor(fs, 16, 64); fs += __shfl_xor(fs, 32, 64); fx += __shfl_xor(fx, 16, 64); fx += __shfl_xor(fx, 32, 64);
-                            if (l4 == 0) { float* s = s_sum + (wv * NFS + ch) * 2; s[0] += fs; s[1] += fx; }      // wave-private slots: no atomics
-                        }
-                    }
+                    XB_T(m3); XB_ACC(3, m3 - m2);                               // rows (issue time)
+                    if (grp == NG - 1) dump = true;
                     lds_barrier();                          // (B1)
+                    XB_T(m5); XB_ACC(5, m5 - m3); XB_ACC(7, 1);                 // wait at B1; passes
                 }
             }
+            XB_T(m6);
             if (ts + 1 < n_strip) lds_barrier();            // (B3)
+            XB_T(m7); XB_ACC(6, m7 - m6);
         }
+        if (dump) dump_tile();
+        lds_barrier();                                      // (BF)
+#ifdef X6B_PROF
+        if (t == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_x6b_prof[i], prof[i]); atomicAdd(&g_x6b_prof[8], 1ull); atomicAdd(&g_x6b_prof[9], xb_now() - t_entry); }
+#endif
         if (fuse_sums) __syncthreads();                     // (Z)
     }
     if (fuse_sums) {
         for (int i = tid; i < NFS * 2; i += 512) {
             const int q = i >> 1, which = i & 1;
             if (q < CI) {
-                float v = (s_sum[(0 * NFS + q) * 2 + which] + s_sum[(1 * NFS + q) * 2 + which]) + (s_sum[(2 * NFS + q) * 2 + which] + s_sum[(3 * NFS + q) * 2 + which]);
+                float v = s_sum[q * 2 + which];
+#pragma unroll
+                for (int w2 = 1; w2 < SUMW; ++w2) v += s_sum[(w2 * NFS + q) * 2 + which];
                 if (which) v *= s_ch[q].rstd;
                 atomicAdd(A.fbsums + ((long long)k * CI + q) * 2 + which, (double)v);
             }
@@ -424,7 +605,7 @@ template <bool K16, int SR, int NG>
 int launch_one(X6BArgs& A, hipStream_t st)
 {
     using C = X6BCfg<K16, SR, NG>;
-    const size_t lds_bytes = (size_t)C::RING + C::WB + sizeof(BwdC) * A.g.Cout + sizeof(ChanFwd) * A.NF * 16 + sizeof(float) * 4 * A.NF * 16 * 2;
+    const size_t lds_bytes = (size_t)C::RING + C::WB + 16 * C::OPB + sizeof(BwdC) * A.g.Cout + sizeof(ChanFwd) * A.NF * 16 + sizeof(float) * C::SUMW * A.NF * 16 * 2;
     if (lds_bytes > 160 * 1024) return -3;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_x6_kernel<K16, SR, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
@@ -492,3 +673,12 @@ int launch_conv_bwd_data_x6(const GView& gy, const ConvGeom& g, const float* w, 
     if (g.Cout == 32) return launch_one<false, 4, 1>(A, st);
     return launch_one<false, 2, 2>(A, st);
 }
+
+#ifdef X6B_PROF
+extern "C" int mfvi_debug_x6b_prof(unsigned long long* out24, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_x6b_prof), sizeof(unsigned long long) * 24);
+    if (e == hipSuccess && reset) { unsigned long long z[24] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_x6b_prof), z, sizeof(z)); }
+    return (int)e;
+}
+#endif

@@ -12,7 +12,7 @@ if [ $# -gt 0 ]; then
     exit 2
 fi
 objs=$(python3 -c "import _build; print(' '.join('build/' + s.replace('.hip', '.o') for s in _build.SOURCES))")
-flags=$(python3 -c "import _build; print(' '.join(_build.FLAGS))")
+flags=$(python3 -c "import _build; print(' '.join(_build.FLAGS + _build.FILE_FLAGS.get('$f.hip', [])))")
 /opt/rocm/bin/hipcc $flags -c csrc/$f.hip -o build/$f.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libmfvi_hip.so $objs
 echo "relinked libmfvi_hip.so"
