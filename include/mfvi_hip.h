@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define MFVI_ABI_VERSION 5
+#define MFVI_ABI_VERSION 6
 
 typedef struct mfvi_plan mfvi_plan;
 
@@ -110,6 +110,18 @@ void mfvi_plan_destroy(mfvi_plan* plan);
  * mfvi_forward uses it too: a skip-branch convolution on a small map (<= MFVI_FWD_FORK pixels, default 128 x 128; 0 = never) runs there
  * beside the down path of its scale and is joined in front of its concat. */
 int mfvi_plan_set_side_stream(mfvi_plan* plan, int enabled);
+/* Device-resident iteration (ABI v6).  The reference's hot loop draws fresh noise every iteration from the loop index i
+ * (bayesian_optimization.py:1360-1372); here that index is the `step` word of the counter RNG.  With a step source set, the plan's
+ * kernels read the counter from DEVICE memory at run time (counter = step argument + *step_dev), so ONE captured HIP graph of an
+ * iteration can be replayed for every i: the caller advances *step_dev on the device (one tiny launch inside the graph) and passes
+ * step = 0.  nullptr (default): the `step` argument is the counter itself.  Results are bit-identical to passing the same counter
+ * values from the host. */
+int mfvi_plan_set_step_source(mfvi_plan* plan, const int32_t* step_dev);
+/* enabled != 0 while the caller captures mfvi_forward / mfvi_backward into a HIP graph (hipStreamBeginCapture on `stream`): fork / join
+ * events between the caller's stream and the plan's side stream are plain hipEventRecord / hipStreamWaitEvent pairs, which stream capture
+ * turns into graph edges (default: they ride on the kernels' dispatch packets, hipExtLaunchKernelGGL, which capture does not record).
+ * The plan must have run once un-captured (tables uploaded, events and the side stream created: none of that may happen under capture). */
+int mfvi_plan_set_capture_mode(mfvi_plan* plan, int enabled);
 /* Gradient split for an overlapped exchange (K sharded over ranks: DESIGN.md section 7; the reference has one process per fit and no exchange,
  * bayesian_optimization.py:3760-3775).  The flat layout is in op order and the backward pass runs the ops last to first, so the weight /
  * bias gradients of the ops >= first_op — the tail [offset, n_vi) of dmu and of drho — are complete long before the pass ends.  With a
@@ -288,6 +300,9 @@ int mfvi_uniform_fill_range(uint64_t seed, uint32_t stream_id, uint32_t sample, 
 int mfvi_add_normal(float* x, uint64_t seed, uint32_t stream_id, uint32_t step, int64_t n, float std, void* stream);
 /* net_input = net_input_saved + std * N(0,1)  (bayesian_optimization.py:1363-1364), RNG domain 1 */
 int mfvi_perturb_input(const float* z0, uint64_t seed, uint32_t step, int64_t n, float std, float* z, void* stream);
+/* the same with the counter word read on the device: step = step_offset + *step_dev (mfvi_plan_set_step_source's convention) */
+int mfvi_perturb_input_dev(const float* z0, uint64_t seed, const int32_t* step_dev, uint32_t step_offset, int64_t n, float std, float* z,
+                           void* stream);
 
 /* ---- per-iteration bookkeeping (bayesian_optimization.py:1374-1406; utils/common_utils.py:297-353) --------- */
 /* acc[0] += mse(a,b) numerator pieces: returns sum (a-b)^2 over n elements into sum_out (device double, overwritten) */

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mfvi_plan_bn_update_running": (_I, [_P, _P, _I, _F, _P, _P]),
     "mfvi_plan_set_bn_eval": (_I, [_P, _P]),
     "mfvi_plan_set_side_stream": (_I, [_P, _I]),
+    "mfvi_plan_set_step_source": (_I, [_P, _P]),
+    "mfvi_plan_set_capture_mode": (_I, [_P, _I]),
     "mfvi_plan_set_grad_split": (_I, [_P, _I, _P]),
     "mfvi_plan_grad_split_offset": (_I, [_P, _I, _P]),
     "mfvi_forward": (_I, [_P, _P, _P, _P, _P, _U64, _U32, _U32, _I, _I, _P, _P, _P]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "mfvi_normal_fill": (_I, [_U64, _U32, _U32, _U32, _U32, _I64, _F, _F, _P, _P]),
     "mfvi_uniform_fill": (_I, [_U64, _U32, _U32, _U32, _I64, _F, _P, _P]),
     "mfvi_perturb_input": (_I, [_P, _U64, _U32, _I64, _F, _P, _P]),
+    "mfvi_perturb_input_dev": (_I, [_P, _U64, _P, _U32, _I64, _F, _P, _P]),
     "mfvi_sq_err_sum": (_I, [_P, _P, _I64, _P, _P]),
     "mfvi_ssim_sum": (_I, [_P, _P, _I, _I, _P, _P]),
     "mfvi_bookkeep": (_I, [_P, _I, _I, _I, _I, _P, _F, _I, _P, _P, _P, _P, _P, _P]),

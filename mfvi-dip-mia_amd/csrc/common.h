@@ -109,7 +109,17 @@ struct RngKey {              // everything but the block index
     uint32_t k0, k1;         // seed lo/hi
     uint32_t stream;         // (domain << 24) | stream id
     uint32_t sample, step;
+    // Device-resident step counter (mfvi_plan_set_step_source, mfvi_perturb_input_dev): when set, `step` is an OFFSET and the counter word
+    // the kernel uses is step + *step_dev, read on the device at run time — so that a captured HIP graph of one iteration replays with
+    // a fresh counter every time (the reference's loop index i, bayesian_optimization.py:1360).  nullptr: `step` is the counter itself.
+    const int32_t* step_dev;
 };
+// first statement of every kernel that takes a key: resolve the device-resident part of the step counter (one scalar load)
+__device__ __forceinline__ RngKey key_now(RngKey k)
+{
+    if (k.step_dev) { k.step += (uint32_t)*k.step_dev; k.step_dev = nullptr; }
+    return k;
+}
 
 // 4 standard normals of Philox block `blk` (elements 4*blk .. 4*blk+3 of the stream)
 __device__ __forceinline__ void spec_normal4(const RngKey& key, uint32_t blk, float z[4])

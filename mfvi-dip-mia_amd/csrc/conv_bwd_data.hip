@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(GView gy, ConvGeom g
                                                             int sample_weights, float* __restrict__ dxp,
                                                             long long dxp_sstride, int tiles_x)
 {
+    key = key_now(key);
     using Cfg = BwdCfg<KS, STRIDE>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH, CIT = Cfg::CIT, COC = Cfg::COC, KK = KS * KS, P = KS / 2;
     constexpr int GT_H = Cfg::GT_H, GT_W = Cfg::GT_W, GT_WP = Cfg::GT_WP;

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(TView in, GView gy
                                                               float* __restrict__ drho, int tiles_x, int n_tiles,
                                                               int tiles_per_block, int ci_tiles)
 {
+    key = key_now(key);
     using Cfg = BwwCfg<KS, STRIDE>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH, COT = Cfg::COT, CIT = Cfg::CIT, KK = KS * KS, P = KS / 2;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, X_PLANE = Cfg::X_PLANE, G_PLANE = Cfg::G_PLANE, ROW = Cfg::ROW;

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(TView in, ConvGeom g, con
                                                        const float* __restrict__ rho, RngKey key, int sample_weights,
                                                        OutDesc out, int tiles_x)
 {
+    key = key_now(key);
     using Cfg = FwdCfg<KS, STRIDE>;
     constexpr int TW = Cfg::TW, PPT = Cfg::PPT, TH = Cfg::TH, CT = Cfg::CT, CC = Cfg::CC, P = Cfg::P;
     constexpr int IN_TH = Cfg::IN_TH, IN_TW = Cfg::IN_TW, IN_TWP = Cfg::IN_TWP, KK = KS * KS;

@@ -527,6 +527,7 @@ __device__ __forceinline__ void lrt_eps4(RngKey key, int layer_id, int k, long l
 __global__ __launch_bounds__(256) void lrt_combine_kernel(const float* __restrict__ a, const float* __restrict__ s2, long long sstride, int C, long long HW,
                                                           RngKey key, int layer_id, OutDesc y)
 {
+    key = key_now(key);
     __shared__ double s_red[8];
     const int k = blockIdx.z, c = blockIdx.y;
     const float* __restrict__ ap = a + (long long)k * sstride + (long long)c * HW;
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(256) void lrt_combine_kernel(const float* __restric
 __global__ __launch_bounds__(256) void lrt_ds2_kernel(GView gy, const float* __restrict__ s2, long long sstride, long long HW, RngKey key, int layer_id,
                                                       float* __restrict__ ds2)
 {
+    key = key_now(key);
     __shared__ ChanBwd s_cb;
     const int k = blockIdx.z, c = blockIdx.y;
     if (threadIdx.x == 0) s_cb = chan_bwd(gy, k, c);

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void mse_channel_kernel(const float* __restric
 // ---- Dropout2d masks (MC-dropout sibling) ----
 __global__ __launch_bounds__(64) void dropout_mask_kernel(const DropEntry* __restrict__ table, RngKey key, float* __restrict__ arena)
 {
+    key = key_now(key);
     const DropEntry e = table[blockIdx.x];
     const int k = blockIdx.y;
     key.stream = ((uint32_t)DOMAIN_DROPOUT << 24) | (uint32_t)e.layer_id;
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256) void decimate_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void normal_fill_kernel(RngKey key, long long n, float a, float b, const float* __restrict__ base,
                                                           float* __restrict__ out)
 {
+    key = key_now(key);
     const long long nblk = (n + 3) >> 2;
     for (long long blk = (long long)blockIdx.x * 256 + threadIdx.x; blk < nblk; blk += (long long)gridDim.x * 256) {
         float z[4]; spec_normal4(key, (uint32_t)blk, z);
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void normal_fill_kernel(RngKey key, long long 
 }
 __global__ __launch_bounds__(256) void uniform_fill_kernel(RngKey key, long long n, float scale, float* __restrict__ out, float lo = 0.f)
 {
+    key = key_now(key);
     const long long nblk = (n + 3) >> 2;
     for (long long blk = (long long)blockIdx.x * 256 + threadIdx.x; blk < nblk; blk += (long long)gridDim.x * 256) {
         uint32_t r[4]; philox4x32_10((uint32_t)blk, key.stream, key.sample, key.step, key.k0, key.k1, r);
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void ring_stats_kernel(const float* __restrict
 inline int nblocks(long long n, int cap = 2048) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 inline RngKey make_key(uint64_t seed, uint32_t domain, uint32_t stream, uint32_t sample, uint32_t step)
 {
-    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = (domain << 24) | stream; k.sample = sample; k.step = step;
+    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = (domain << 24) | stream; k.sample = sample; k.step = step; k.step_dev = nullptr;
     return k;
 }
 
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
                                                             float* __restrict__ dmu, float* __restrict__ drho,
                                                             const float* __restrict__ wsamp, long long wstride, const void* __restrict__ mu_v)
 {
+    key = key_now(key);
     typedef typename std::conditional<BF16, bf16_t, float>::type PT;
     const PT* __restrict__ rho = static_cast<const PT*>(rho_v); const PT* __restrict__ mu = static_cast<const PT*>(mu_v);
     auto ld = [](const PT* q) -> float { if constexpr (BF16) return bf16_to_f32(*q); else return *q; };
@@ -597,6 +601,7 @@ __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* 
                                                              const void* __restrict__ mu_v, const void* __restrict__ rho_v,
                                                              RngKey key, float* __restrict__ wsamp, long long wstride, int sample)
 {
+    key = key_now(key);
     typedef typename std::conditional<BF16, bf16_t, float>::type PT;
     const PT* __restrict__ mu = static_cast<const PT*>(mu_v); const PT* __restrict__ rho = static_cast<const PT*>(rho_v);
     __shared__ int s_first[TABLE_LDS];
@@ -653,6 +658,7 @@ __global__ __launch_bounds__(256) void elbo_update_bf16_kernel(bf16_t* __restric
                                                                float b1, float b2, float eps, float step_size, float inv_sqrt_bc2, RngKey key,
                                                                ElboUpdateScratch* __restrict__ sc)
 {
+    key = key_now(key);
     __shared__ double s_red[8];
     const float log_s0 = logf(s0), s0sq = s0 * s0;
     auto adam = [&](long long i, float gi, float pi) -> float {
@@ -962,6 +968,15 @@ int mfvi_perturb_input(const float* z0, uint64_t seed, uint32_t step, int64_t n,
     if (n <= 0) return 0;
     hipLaunchKernelGGL(normal_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        make_key(seed, DOMAIN_INPUT, 0, 0, step), (long long)n, 0.f, std, z0, z);
+    return (int)hipGetLastError();
+}
+
+int mfvi_perturb_input_dev(const float* z0, uint64_t seed, const int32_t* step_dev, uint32_t step_offset, int64_t n, float std, float* z, void* stream)
+{
+    if (!step_dev) { set_error("perturb_input_dev: null step counter"); return -1; }
+    if (n <= 0) return 0;
+    RngKey key = make_key(seed, DOMAIN_INPUT, 0, 0, step_offset); key.step_dev = step_dev;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3(nblocks((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, key, (long long)n, 0.f, std, z0, z);
     return (int)hipGetLastError();
 }
 

@@ -65,6 +65,8 @@ struct mfvi_plan {
     X6SplitEntry* x6_dev = nullptr; std::vector<X6SplitEntry> x6_uploaded;      // table of the bf16x6 forward layers' weight split (conv_x6.hip)
     X6BSplitEntry* x6b_dev = nullptr; std::vector<X6BSplitEntry> x6b_uploaded;   // the same for the bf16x6 backward-data layers (conv_bwd_x6.hip)
     int param_dtype = MFVI_PARAM_F32;          // storage of mu / rho handed to forward / backward (MFVI_PARAM_BF16: bf16_t arrays)
+    const int32_t* step_dev = nullptr;         // device-resident step counter (mfvi_plan_set_step_source): the `step` argument of forward / backward is an offset to it
+    bool capture_mode = false;                 // the calls are being captured into a HIP graph: fork / join events as plain records (no events on kernel packets)
     int n_generic = 0;                         // conv layers outside the sampling table (served by the generic fp32 kernels)
     long long p32_off = -1;                    // floats: [mu | rho] expanded to float32 for those kernels when mu / rho are bf16
     const float* bn_eval = nullptr;            // BatchNorm in eval mode: running statistics used by mfvi_forward (nullptr: batch statistics)
@@ -405,9 +407,9 @@ int fold_consumers(mfvi_plan* plan, const Ctx& c, int tid, const TView& xin, flo
     return launch_finalize_dx(srcs, ns, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
 }
 
-RngKey base_key(uint64_t seed, uint32_t step, uint32_t k0)
+RngKey base_key(uint64_t seed, uint32_t step, uint32_t k0, const int32_t* step_dev = nullptr)
 {
-    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = 0; k.sample = k0; k.step = step; return k;
+    RngKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32); k.stream = 0; k.sample = k0; k.step = step; k.step_dev = step_dev; return k;
 }
 
 }  // namespace
@@ -483,6 +485,20 @@ int mfvi_plan_set_grad_split(mfvi_plan* plan, int first_op, void* comm_stream)
     return 0;
 }
 
+int mfvi_plan_set_step_source(mfvi_plan* plan, const int32_t* step_dev)
+{
+    if (!plan) { set_error("set_step_source: null plan"); return -1; }
+    plan->step_dev = step_dev; plan->samp_n = 0;
+    return 0;
+}
+
+int mfvi_plan_set_capture_mode(mfvi_plan* plan, int enabled)
+{
+    if (!plan) { set_error("set_capture_mode: null plan"); return -1; }
+    plan->capture_mode = enabled != 0;
+    return 0;
+}
+
 int mfvi_plan_set_param_dtype(mfvi_plan* plan, int dtype)
 {
     if (!plan || (dtype != MFVI_PARAM_F32 && dtype != MFVI_PARAM_BF16)) { set_error("set_param_dtype: bad arguments"); return -1; }
@@ -545,7 +561,7 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
         plan->bsums_clean_ws = workspace;
     }
-    const RngKey key = base_key(seed, step, k0);
+    const RngKey key = base_key(seed, step, k0, plan->step_dev);
     if (plan->bn_eval && plan->n_entries) {   // nn.BatchNorm2d in eval mode: the running statistics stand in for every sample's batch sums
         const int rc = launch_bn_eval_fill(plan->table_dev, plan->n_entries, plan->max_c, c.fstats(), n_samples, plan->bn_eval, st);
         if (rc) { set_error("forward: bn_eval_fill launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
@@ -611,7 +627,8 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
     };
     // events on the kernels' own packets where the launch goes through mfvi_launch (as in mfvi_backward): the fork event of op i + 1 on op i's
     // launch, the join event on the forked launch itself
-    static const bool on_packet = [] { const char* e = getenv("MFVI_FORK_ON_PACKET"); return !(e && e[0] == '0'); }();
+    static const bool on_packet_env = [] { const char* e = getenv("MFVI_FORK_ON_PACKET"); return !(e && e[0] == '0'); }();
+    const bool on_packet = on_packet_env && !plan->capture_mode;
     hipEvent_t pre_ev = nullptr; size_t pre_for = (size_t)-1; bool pre_done = false; int pre_idx = -1;
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         const OpInfo& o = plan->ops[i];
@@ -712,7 +729,7 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         if (e != hipSuccess) { set_error("backward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     plan->bsums_clean_ws = nullptr;
-    const RngKey key = base_key(seed, step, k0);
+    const RngKey key = base_key(seed, step, k0, plan->step_dev);
     if (plan->n_lrt && sample_weights) {
         if (!rho) { set_error("backward: local-reparameterisation layers take float32 parameters"); return -1; }
         hipError_t e = hipMemsetAsync(c.farena() + plan->dsig2_off, 0, sizeof(float) * plan->n_vi, st);
@@ -778,7 +795,8 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     // The fork event of the NEXT op's backward-weight kernel rides on the packet of this op's last launch on the caller's stream when that
     // launch goes through mfvi_launch (armed right before it; a launcher that takes another path leaves it armed and the fork falls back to
     // hipEventRecord).  MFVI_FORK_ON_PACKET=0: always hipEventRecord.
-    static const bool fork_on_packet = [] { const char* e = getenv("MFVI_FORK_ON_PACKET"); return !(e && e[0] == '0'); }();
+    static const bool fork_on_packet_env = [] { const char* e = getenv("MFVI_FORK_ON_PACKET"); return !(e && e[0] == '0'); }();
+    const bool fork_on_packet = fork_on_packet_env && !plan->capture_mode;
     int armed_idx = -1;
     auto will_fork = [&](int j) {
         if (j < 0 || side == st || plan->ops[j].d.type != MFVI_OP_CONV) return false;

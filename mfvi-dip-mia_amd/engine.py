@@ -82,6 +82,8 @@ class ElboEngine:
             self.theta = torch.tensor(th, dtype=torch.float32, device=dev)
             self.ct_scratch = torch.empty(self.chunk * len(th) * W, dtype=torch.float32, device=dev)
         self.t = 0
+        self.step_dev = None             # device-resident iteration (enable_device_step / enable_graph): the RNG step counter on the device
+        self._graph = None
         self.target = None
         self.sample_weights = True       # w = mu + softplus(rho) * eps; the non-Bayesian siblings run w = mu
         self.init_params()
@@ -124,12 +126,21 @@ class ElboEngine:
         lib, sp = L.lib(), L.stream_ptr()
         step = self.t if step is None else step
         if perturb:
-            L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
+            self._perturb(step)
+        if self.step_dev is not None:
+            step = 0                      # an offset to the device counter
         for c0 in range(0, self.K_local, self.chunk):
             n = min(self.chunk, self.K_local - c0)
             self.plan.forward(self.mu, self.rho, self.bn, self.z if perturb else self.z0, self.seed, step, self.k0 + c0, n, self.sample_weights,
                               self.out)
         return self.out
+
+    def _perturb(self, step):
+        lib, sp = L.lib(), L.stream_ptr()
+        if self.step_dev is not None:      # counter = *step_dev (+ 0) read on the device
+            L.check(lib.mfvi_perturb_input_dev(L.ptr(self.z0), self.seed, L.ptr(self.step_dev), 0, self.z0.numel(), 0.1, L.ptr(self.z), sp))
+        else:
+            L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
 
     def _loss_and_dout(self, n):
         lib, sp = L.lib(), L.stream_ptr()
@@ -153,8 +164,10 @@ class ElboEngine:
         exchange = self.world > 1 or getattr(self, "_force_exchange", False)
         zsrc = self.z0
         if perturb:
-            L.check(lib.mfvi_perturb_input(L.ptr(self.z0), self.seed, step, self.z0.numel(), 0.1, L.ptr(self.z), sp))
+            self._perturb(step)
             zsrc = self.z
+        if self.step_dev is not None:
+            step = 0                      # an offset to the device counter
         for c0 in range(0, self.K_local, self.chunk):
             n = min(self.chunk, self.K_local - c0)
             self.plan.forward(self.mu, self.rho, self.bn, zsrc, self.seed, step, self.k0 + c0, n, self.sample_weights, self.out)
@@ -245,11 +258,62 @@ class ElboEngine:
         L.check(lib.mfvi_bf16_to_f32(L.ptr(self.rho), self.n_vi, L.ptr(out[self.n_vi:]), sp))
         return out[:self.n_vi], out[self.n_vi:], self.bn
 
+    def enable_device_step(self):
+        """Device-resident iteration state: the RNG step counter (the reference's loop index i, bayesian_optimization.py:1360) and Adam's
+        update count live in device memory — the kernels read them there (mfvi_plan_set_step_source; the update through the device counter
+        of mfvi_elbo_update_guarded) and a one-element add inside the iteration advances the step.  Same arithmetic as the host-driven path;
+        what it buys is that an iteration no longer depends on any host value: it can be captured once and replayed (enable_graph)."""
+        if self.param_dtype == "bf16" or type(self) is not ElboEngine:
+            raise NotImplementedError("the device-resident iteration is built for the float32 MFVI engine")
+        if self.step_dev is None:
+            torch = self.torch
+            self.step_dev = torch.full((1,), self.t, dtype=torch.int32, device="cuda")
+            self.t_applied.fill_(self.t)                      # Adam's count of applied updates (CT: the NaN guard may hold it back)
+            L.check(L.lib().mfvi_plan_set_step_source(self.plan.handle, L.ptr(self.step_dev)))
+        return self
+
+    def _device_iteration(self, after_forward=None):
+        lib, sp = L.lib(), L.stream_ptr()
+        self.grad_only(0, with_kl=False, after_forward=after_forward)
+        guard = self._guard() if self.task == TASK_CT else (None, None)
+        L.check(lib.mfvi_elbo_update_guarded(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.m), L.ptr(self.v), self.n_vi, self.n_bn, 0.0,
+                                             self.prior_sigma, self.temp, self.lr, 0.9, 0.999, 1e-8, L.ptr(self.t_applied), *guard,
+                                             L.ptr(self.acc[1:]), L.ptr(self.upd_scratch), sp))
+        self.step_dev.add_(1)
+
+    def enable_graph(self, warmup=3):
+        """Capture ONE iteration (both streams of the plan, fork / join events as graph edges) into a HIP graph and replay it from then on:
+        step() becomes one hipGraphLaunch.  `warmup` un-captured iterations run first (tables uploaded, side stream and events created —
+        nothing may be allocated under capture).  The loop being matched: bayesian_optimization.py:1360-1372."""
+        torch = self.torch
+        self.enable_device_step()
+        if self.world > 1:
+            raise NotImplementedError("graph capture of the K-sharded iteration (the all-reduce inside the graph) is not built")
+        for _ in range(max(1, warmup)):
+            self._device_iteration(); self.t += 1
+        torch.cuda.synchronize()
+        L.check(L.lib().mfvi_plan_set_capture_mode(self.plan.handle, 1))
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self._device_iteration()
+        finally:
+            L.check(L.lib().mfvi_plan_set_capture_mode(self.plan.handle, 0))
+        # the capture itself executes nothing: the counters still say "iteration self.t"
+        self._graph = g
+        return self
+
     def step(self, after_forward=None):
         """One ELBO iteration: K forwards + NLL + backward + (all-reduce), then KL + its gradient + Adam in one fused launch
         (identical on every rank: no communication).  after_forward: optional callable f(n) run once the last forward (n samples in self.out) + data term of the
         iteration are enqueued (the runners start their per-iteration bookkeeping there, on a second stream beside the backward pass)."""
         lib, sp = L.lib(), L.stream_ptr()
+        if self._graph is not None and after_forward is None:
+            self._graph.replay(); self.t += 1
+            return
+        if self.step_dev is not None:
+            self._device_iteration(after_forward); self.t += 1
+            return
         self.grad_only(self.t, with_kl=False, after_forward=after_forward)
         self.t += 1
         if self.param_dtype == "bf16":
