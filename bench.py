@@ -423,6 +423,7 @@ def main():
     ap.add_argument("--k", type=int, default=None, help="override the config's MC samples (per GPU in weak mode, per job in strong mode)")
     ap.add_argument("--mode", default="engine", choices=["engine", "dropin"])
     ap.add_argument("--flat-parameters", action="store_true", help="--mode dropin: MeanFieldVI(..., flat_parameters=True) (one flat Parameter for the optimizer)")
+    ap.add_argument("--graph", action="store_true", help="--mode engine, one GPU: capture one iteration into a HIP graph (device-resident step counters) and time its replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true", help="skip the unfused PyTorch-ROCm leg (SURVEY 8d's same-node row)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel time table of one iteration to stderr")
@@ -564,7 +565,15 @@ def main():
         eng._ar_events = []
         for _ in range(2):
             eng.step()
-    eng.plan.profile(2, dom_op, dom_pass)
+    graph_info = None
+    if args.graph:
+        if world > 1 or args.mode != "engine":
+            sys.exit("--graph: the fused engine on one GPU")
+        eng.enable_graph(warmup=3)
+        for _ in range(3):
+            eng.step()
+        graph_info = {"captured": True, "what": "one ELBO iteration (both streams of the plan) as ONE hipGraphLaunch; RNG step counter and Adam's update count read from device memory"}
+    eng.plan.profile(0 if args.graph else 2, dom_op, dom_pass)      # (a replayed graph carries no per-kernel events)
     dt = timed(eng, args.steps)
     recs = eng.plan.profile_read()
     eng.plan.profile(0)
@@ -584,7 +593,7 @@ def main():
 
     if rank == 0:
         kms = [ms for _, _, ms in recs]
-        avg_ms = sum(kms) / max(len(kms), 1)
+        avg_ms = sum(kms) / max(len(kms), 1) if kms else by[(dom_op, dom_pass)] / n_launch      # --graph: the instrumented iteration's duration
         cost = conv_cost(eng.prog, dom_op, eng.chunk)
         ai = cost["flops"] / cost["bytes"]
         ridge = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
@@ -655,6 +664,8 @@ def main():
             res["bf16x6_kernels"] = x6
         except Exception:
             res["bf16x6_kernels"] = None
+        if graph_info:
+            res["graph"] = graph_info
         if strong_extra:
             res["strong_scaling"] = strong_extra
         if world > 1:

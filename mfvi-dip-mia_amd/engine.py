@@ -281,7 +281,7 @@ class ElboEngine:
                                              L.ptr(self.acc[1:]), L.ptr(self.upd_scratch), sp))
         self.step_dev.add_(1)
 
-    def enable_graph(self, warmup=3):
+    def enable_graph(self, warmup=3, side_stream=None):
         """Capture ONE iteration (both streams of the plan, fork / join events as graph edges) into a HIP graph and replay it from then on:
         step() becomes one hipGraphLaunch.  `warmup` un-captured iterations run first (tables uploaded, side stream and events created —
         nothing may be allocated under capture).  The loop being matched: bayesian_optimization.py:1360-1372."""
@@ -289,6 +289,11 @@ class ElboEngine:
         self.enable_device_step()
         if self.world > 1:
             raise NotImplementedError("graph capture of the K-sharded iteration (the all-reduce inside the graph) is not built")
+        if side_stream is None:
+            import os
+            side_stream = os.environ.get("MFVI_GRAPH_SIDE", "1") != "0"
+        if not side_stream:      # one linear chain of kernel nodes (no fork / join edges)
+            self.plan.side_stream(False)
         for _ in range(max(1, warmup)):
             self._device_iteration(); self.t += 1
         torch.cuda.synchronize()
