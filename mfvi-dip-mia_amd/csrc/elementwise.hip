@@ -8,6 +8,7 @@
 //                     BN-backward sums of A and B
 //   bn_param_grads  : d gamma / d beta from the accumulated sums
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -261,6 +262,105 @@ __global__ __launch_bounds__(256) void concat_up_fwd_vec_kernel(TView a, int has
         { const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
           const float q4 = __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
           sum += (double)s4; sq += (double)q4; }
+    }
+    if (out.stats != nullptr) {
+        const double sa = block_sum_d(sum, s_red);
+        const double sb = block_sum_d(sq, s_red);
+        if (t == 0) { double* st = out.stats + ((long long)k * Ct + c) * 2; atomicAdd(st, sa); atomicAdd(st + 1, sb); }
+    }
+}
+
+// concat_up forward for maps at least 128 wide (round 4): LDS-tiled.  A block = (sample, concat channel, tile of CF_TH x CF_TW LOW-res
+// pixels = 2 CF_TH x 2 CF_TW outputs).  The vector kernel above fetches eight scalars per float4 of output (two low-res rows x four clamped
+// columns per lane, every low-res value loaded by four lanes): 2.2 load instructions per output row segment, 3 TB/s at 256^2.  Here the
+// low-res window (CF_TH + 2 rows x CF_TW + 2 columns, clamped at the image border exactly as up_coef / the vector kernel clamp) is loaded ONCE,
+// coalesced, transformed (deferred BN + LeakyReLU of the low-res tensor) and kept in LDS; every lane then reads its 2 x 4 taps as aligned
+// float2 pairs and blends with the SAME arithmetic (results bit-identical to the vector kernel: tests/test_gpu_parity.py).  Channels of the
+// skip branch are an element-wise copy with the view applied, as before.
+constexpr int CF_TH = 8, CF_TW = 64, CF_PITCH = CF_TW + 4;      // even pitch: the float2 reads of consecutive lanes are consecutive
+__global__ __launch_bounds__(256) void concat_up_fwd_tiled_kernel(TView a, int has_a, TView b, OutDesc out, int H, int W, int nearest, int tiles_x, int n_tiles)
+{
+    __shared__ ChanFwd s_ch;
+    __shared__ double s_red[8];
+    __shared__ __align__(8) float s_lo[CF_TH + 2][CF_PITCH];
+    const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
+    const int Ca = has_a ? a.C : 0, Ct = Ca + b.C;
+    const long long HW = (long long)H * W;
+    const bool from_a = c < Ca;
+    if (t == 0) s_ch = from_a ? chan_fwd(a, k, c) : chan_fwd(b, k, c - Ca);
+    float* __restrict__ o = out.data + (long long)k * out.sstride + (long long)c * HW;
+    double sum = 0.0, sq = 0.0;
+    constexpr int NG = 2 * CF_TH * (2 * CF_TW / 4) / 256;      // float4 groups per thread
+    __syncthreads();
+    const ChanFwd ch = s_ch;
+    // tiles blockIdx.x, blockIdx.x + gridDim.x, ... : several tiles per block amortise the channel constants and the block reduction
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int m0 = (tile / tiles_x) * CF_TH, n0 = (tile % tiles_x) * CF_TW;      // low-res tile origin
+    const int r0 = 2 * m0, q0 = 2 * n0;
+    if (from_a) {
+        const float* __restrict__ src = a.data + (long long)k * a.sstride + (long long)c * HW;
+        float4 y[NG]; bool ok[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = t + 256 * j, r = r0 + idx / (2 * CF_TW / 4), q = q0 + 4 * (idx % (2 * CF_TW / 4));
+            ok[j] = r < H && q < W;
+            y[j] = ok[j] ? *reinterpret_cast<const float4*>(src + (long long)r * W + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            if (!ok[j]) continue;
+            const int idx = t + 256 * j, r = r0 + idx / (2 * CF_TW / 4), q = q0 + 4 * (idx % (2 * CF_TW / 4));
+            float v[4] = {apply_fwd(ch, y[j].x, a.act, a.slope), apply_fwd(ch, y[j].y, a.act, a.slope), apply_fwd(ch, y[j].z, a.act, a.slope), apply_fwd(ch, y[j].w, a.act, a.slope)};
+            *reinterpret_cast<float4*>(o + (long long)r * W + q) = make_float4(v[0], v[1], v[2], v[3]);
+            const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+            const float q4 = __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
+            sum += (double)s4; sq += (double)q4;
+        }
+    } else {
+        const float* __restrict__ p = b.data + (long long)k * b.sstride + (long long)(c - Ca) * b.H * b.W;
+        constexpr int NL = ((CF_TH + 2) * (CF_TW + 2) + 255) / 256;
+        float raw[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int idx = min(t + 256 * j, (CF_TH + 2) * (CF_TW + 2) - 1), lr = idx / (CF_TW + 2), lc = idx - lr * (CF_TW + 2);
+            const int yy = min(max(m0 - 1 + lr, 0), b.H - 1), xx = min(max(n0 - 1 + lc, 0), b.W - 1);
+            raw[j] = p[yy * b.W + xx];
+        }
+        __syncthreads();                                   // the previous tile's reads of s_lo are done
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int idx = t + 256 * j, lr = idx / (CF_TW + 2), lc = idx - lr * (CF_TW + 2);
+            if (idx < (CF_TH + 2) * (CF_TW + 2)) s_lo[lr][lc] = apply_fwd(ch, raw[j], b.act, b.slope);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = t + 256 * j, col4 = idx % (2 * CF_TW / 4), r = r0 + idx / (2 * CF_TW / 4), q = q0 + 4 * col4;
+            if (r >= H || q >= W) continue;
+            int y0, y1; float ly;
+            up_coef(r, b.H, y0, y1, ly);
+            if (nearest) { y0 = y1 = r >> 1; ly = 0.f; }
+            // low-res columns q/2 - 1 .. q/2 + 2 (clamped when staged) = local columns 2 col4 .. 2 col4 + 3
+            const float2 l0 = *reinterpret_cast<const float2*>(&s_lo[y0 - m0 + 1][2 * col4]), l1 = *reinterpret_cast<const float2*>(&s_lo[y0 - m0 + 1][2 * col4 + 2]);
+            const float2 h0 = *reinterpret_cast<const float2*>(&s_lo[y1 - m0 + 1][2 * col4]), h1 = *reinterpret_cast<const float2*>(&s_lo[y1 - m0 + 1][2 * col4 + 2]);
+            const float lo[4] = {l0.x, l0.y, l1.x, l1.y}, hi[4] = {h0.x, h0.y, h1.x, h1.y};
+            const bool left = q == 0;
+            const int i0[4] = {0, 1, 1, 2};
+            const float lxs[4] = {left ? 0.f : 0.75f, 0.25f, 0.75f, 0.25f};
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int ia = nearest ? 1 + (jj >> 1) : ((jj == 0 && left) ? 1 : i0[jj]);
+                const float lx = nearest ? 0.f : lxs[jj];
+                const float v00 = lo[ia], v01 = lo[ia + 1], v10 = hi[ia], v11 = hi[ia + 1];
+                v[jj] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            }
+            *reinterpret_cast<float4*>(o + (long long)r * W + q) = make_float4(v[0], v[1], v[2], v[3]);
+            const float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+            const float q4 = __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
+            sum += (double)s4; sq += (double)q4;
+        }
+    }
     }
     if (out.stats != nullptr) {
         const double sa = block_sum_d(sum, s_red);
@@ -636,6 +736,14 @@ int launch_concat_up_fwd(const TView* a, const TView& b, OutDesc out, int neares
     const long long HW = (long long)H * W;
     TView av = a ? *a : b;
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    static const int tiled_min_w = [] { const char* e = getenv("MFVI_CONCAT_TILED"); return e ? atoi(e) : 128; }();      // MFVI_CONCAT_TILED=0: never (A/B)
+    if (tiled_min_w > 0 && (W & 3) == 0 && W >= tiled_min_w && (out.sstride & 3) == 0 && al16(out.data) && (!a || ((a->sstride & 3) == 0 && al16(a->data)))) {
+        const int tiles_x = (b.W + CF_TW - 1) / CF_TW, tiles_y = (b.H + CF_TH - 1) / CF_TH;
+        static const int tpb = [] { const char* e = getenv("MFVI_CONCAT_TPB"); return e ? atoi(e) : 4; }();
+        const int n_tiles = tiles_x * tiles_y;
+        hipLaunchKernelGGL(concat_up_fwd_tiled_kernel, dim3((n_tiles + tpb - 1) / tpb, Ct, n_samples), dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W, nearest, tiles_x, n_tiles);
+        return (int)hipGetLastError();
+    }
     if ((W & 3) == 0 && (out.sstride & 3) == 0 && al16(out.data) && (!a || ((a->sstride & 3) == 0 && al16(a->data)))) {
         dim3 grid((unsigned)((HW / 4 + 256 * V_GROUPS - 1) / (256 * V_GROUPS)), Ct, n_samples);
         hipLaunchKernelGGL(concat_up_fwd_vec_kernel, grid, dim3(256), 0, st, av, a ? 1 : 0, b, out, H, W, nearest);
