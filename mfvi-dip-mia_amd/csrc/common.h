@@ -397,6 +397,12 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not 
 #define MFVI_TUNE_X6 (1 << 25)
 // small-map forward (conv_small.hip): the whole reduction of a (sample, 16 output channels, 64 pixels) block in LDS, one stage; tune bit 26
 #define MFVI_TUNE_SM (1 << 26)
+// "in-kernel eps" (tune bit 27, any of the three passes): the layer runs on the generic kernels of conv_fwd.hip / conv_bwd_*.hip, which draw eps, form
+// w = mu + softplus(rho) * eps and convolve in ONE launch (BayTorch/modules/module.py:82-85 + reparam_layers.py:28-37, as BASELINE's north_star
+// words it) — no sampled-weight slab, eps bit-identical by the RNG spec.  A candidate of the autotuner for layers of at most MFVI_INKERNEL_MAX_W
+// weights (every 1x1 skip convolution, the 16 -> 16 layers): kept where it is at least as fast as the matrix-core kernel reading the slab.
+#define MFVI_TUNE_GENERIC (1 << 27)
+#define MFVI_INKERNEL_MAX_W 2560
 int launch_conv_fwd_small(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
 int launch_conv_bwd_data_small(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int n_samples, hipStream_t st, const FoldFuse& fuse);
 extern thread_local float* mfvi_tl_x6w;

@@ -671,6 +671,7 @@ int launch_conv_bwd_weight_mfma(const TView& in, const GView& gy, const ConvGeom
                                 hipStream_t st)
 {
     if (!part.base || part.max_strips < 1 || (g.Cin & 3) || (g.w_off & 3)) return -2;
+    if (g.tune[2] & MFVI_TUNE_GENERIC) return -2;                           // in-kernel eps: the generic kernel accumulates d mu / d rho itself
     int cfg = g.tune[2] ? g.tune[2] : env_tune_w();
     const bool forced = cfg != 0;
     if (!cfg) {

@@ -1177,6 +1177,7 @@ int launch_variant(const TView& xin, const GView& gin, const ConvGeom& g, const 
 int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st)
 {
     if (g.Cin > MFVI_MAX_C || (g.Cin & 3) || (g.w_off & 3)) return -2;      // Philox blocks must tile every weight row
+    if (g.tune[0] & MFVI_TUNE_GENERIC) return -2;                           // in-kernel eps: the generic kernel draws and convolves in one launch
     if ((long long)g.Cout * g.Ho * g.Wo >= (1LL << 31)) return -2;          // the epilogue uses 32-bit element offsets per sample
     // aligned float4 staging: image rows, sample strides and the base pointer must be multiples of 4 floats
     if ((g.W & 3) || g.W < 4 || (in.sstride & 3) || ((uintptr_t)in.data & 15)) return -2;
@@ -1213,6 +1214,7 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
                               int n_samples, hipStream_t st, const FoldFuse* fuse)
 {
     if (g.Cout > MFVI_MAX_C || (g.stride != 1 && !(g.stride == 2 && g.ks >= 3)) || (g.Cin & 3) || (g.w_off & 3)) return -2;
+    if (g.tune[1] & MFVI_TUNE_GENERIC) return -2;
     if ((long long)g.Cin * (g.H + 4) * (g.W + 4) >= (1LL << 31)) return -2;   // 32-bit element offsets per sample
     // aligned float4 (stride 2: float2) staging of the gradient and of the conv output it is normalised with
     const int wa = g.stride == 2 ? 1 : 3;

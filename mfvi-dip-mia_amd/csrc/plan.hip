@@ -1117,7 +1117,15 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
         for (int which = 0; which < 3; ++which) {
             if (which == 1 && o.d.in0 == plan->input) continue;
             int strips_used = 0;
+            const float* mu32 = plan->param_dtype == MFVI_PARAM_F32 ? static_cast<const float*>(mu) : nullptr;
+            const float* rho32 = plan->param_dtype == MFVI_PARAM_F32 ? static_cast<const float*>(rho) : nullptr;
+            const bool tiny = mu32 && (long long)o.g.Cout * o.g.Cin * o.g.ks * o.g.ks <= MFVI_INKERNEL_MAX_W;
             auto launch = [&]() {
+                if (o.g.tune[which] & MFVI_TUNE_GENERIC) {      // in-kernel eps: the generic kernels, exactly as mfvi_forward / mfvi_backward reach them
+                    if (which == 0) return launch_conv_fwd(xin, o.g, mu32, rho32, key, 1, od, n_samples, st);
+                    if (which == 1) return launch_conv_bwd_data(gy, o.g, mu32, rho32, key, 1, c.farena() + o.scratch_off, per, n_samples, st);
+                    return launch_conv_bwd_weight(xin, gy, o.g, rho32, key, 1, dmu, drho, n_samples, st);
+                }
                 if (which == 0) {
                     mfvi_tl_x6w = o.x6w_off >= 0 ? c.farena() + o.x6w_off : nullptr;
                     const int r0 = launch_conv_fwd_mfma(xin, o.g, c.wsamp(), plan->n_vi, od, n_samples, st);
@@ -1167,6 +1175,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                 if (o.g.ks == 3 && o.g.stride == 1 && (o.g.W & 31) == 0)                         // bf16x6 kernel (conv_bww_x6.hip)
                     for (int cof = 1; cof <= 2; ++cof) for (int tb = 1; tb <= 4; tb *= 2) cands.push_back(cof | 11 << 8 | tb << 16);
             }
+            if (tiny && which != 1) cands.push_back(MFVI_TUNE_GENERIC);      // (backward-data: the fused fold of the matrix-core path is not what the generic kernel replaces)
             int best = 0; float best_ms = 1e30f;
             for (int cand : cands) {
                 o.g.tune[which] = cand;
