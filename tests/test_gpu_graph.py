@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+def _same_losses(a, b):
+    """the loss accumulators are float64 sums by atomic adds (order not fixed from run to run): equal to the last few bits, not bit for bit"""
+    return all(abs(x - y) <= 1e-12 * max(abs(y), 1e-30) for x, y in zip(a, b))
+
+
 def _engine(task, K, S=64, **kw):
     from mfvi_dip_mia_amd.engine import ElboEngine
     eng = ElboEngine(S, S, task=task, K=K, input_depth=8, temp=5.7e-7, sigma=1.5e-5, lr=1e-3, seed=11,
@@ -40,7 +45,7 @@ def test_device_step_and_graph_replay_are_bit_identical(task, K):
         dev.step()
     assert int(dev.step_dev) == n and int(dev.t_applied) == n
     assert torch.equal(dev.params, ref.params), "device-resident counters changed the trajectory"
-    assert dev.losses() == ref_losses
+    assert _same_losses(dev.losses(), ref_losses)
     # one captured graph, replayed (3 un-captured warm-up iterations + 6 replays)
     gr = _engine(task, K).enable_graph(warmup=3)
     assert gr._graph is not None and gr.t == 3
@@ -49,7 +54,7 @@ def test_device_step_and_graph_replay_are_bit_identical(task, K):
     torch.cuda.synchronize()
     assert int(gr.step_dev) == n
     assert torch.equal(gr.params, ref.params), "graph replay changed the trajectory"
-    assert gr.losses() == ref_losses
+    assert _same_losses(gr.losses(), ref_losses)
     assert torch.equal(gr.m, ref.m) and torch.equal(gr.v, ref.v)
 
 
