@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmfvi_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_bwd_x6.hip", "conv_small.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
+SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_bwd_x6.hip", "conv_small.hip", "conv_1x1.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras.  conv_bwd_x6: no SLP vectorisation — packed fp32 instructions (v_pk_add / v_pk_fma) beside a matrix stream cost more issue time
 # than the scalar ones they replace (MI355X_MICROARCH.md; measured on this kernel: 68->32 @128^2 88.0 -> 78.8 us); the explicit pairs of the

@@ -405,6 +405,9 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not 
 #define MFVI_INKERNEL_MAX_W 2560
 int launch_conv_fwd_small(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
 int launch_conv_bwd_data_small(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int n_samples, hipStream_t st, const FoldFuse& fuse);
+// One-stage 1x1 kernels (conv_1x1.hip): 16 | Cin, Cout <= 128, H*W a multiple of 64; same tune bit (MFVI_TUNE_SM) on a 1x1 layer; -2: shape not served
+int launch_conv1_fwd_small(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
+int launch_conv1_bwd_data_small(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int n_samples, hipStream_t st, const FoldFuse& fuse);
 extern thread_local float* mfvi_tl_x6w;
 extern thread_local bool mfvi_tl_x6w_ready;      // the pieces of this pass are already in the scratch (launch_x6_split_all)
 long long x6_fwd_scratch_floats(const ConvGeom& g, int n_samples);

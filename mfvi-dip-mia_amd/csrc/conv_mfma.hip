@@ -1184,7 +1184,7 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
     {   // row-phase kernels (conv_rp.hip): an explicit tiling of the plan / autotuner, or the default for the shapes they serve
         int tn = g.tune[0] ? g.tune[0] : (env_tune() ? 0 : rp_default_tune(g, 0, n_samples));
         if (tn & MFVI_TUNE_SM) {      // small-map forward (conv_small.hip): only as an explicit tiling of the plan / autotuner
-            const int rc = launch_conv_fwd_small(in, g, w, wstride, out, n_samples, st);
+            const int rc = g.ks == 1 ? launch_conv1_fwd_small(in, g, w, wstride, out, n_samples, st) : launch_conv_fwd_small(in, g, w, wstride, out, n_samples, st);
             return rc == -2 ? -3 : rc;
         }
         if (tn & MFVI_TUNE_X6) {      // bf16x6 forward (conv_x6.hip): only as an explicit tiling of the plan / autotuner
@@ -1245,6 +1245,10 @@ int launch_conv_bwd_data_mfma(const GView& gy, const ConvGeom& g, const float* w
             }
         }
         if (g.ks == 3) return launch_variant<3, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
+        if (g.tune[1] & MFVI_TUNE_SM) {      // one-stage 1x1 kernel (conv_1x1.hip): only as an explicit tiling of the plan / autotuner
+            const int rc = launch_conv1_bwd_data_small(gy, g, w, wstride, n_samples, st, *fuse);
+            return rc == -2 ? -3 : rc;
+        }
         return launch_variant<1, 1, 1>(fuse->x, gy, g, w, wstride, od, nullptr, 0, n_samples, st, *fuse);
     }
     if (g.ks == 3) return launch_variant<3, 1, 1>(none, gy, g, w, wstride, od, dxp, dxp_sstride, n_samples, st);

@@ -1164,6 +1164,9 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                         cands.push_back(mf | 1 << 8 | rem << 12 | ks << 13 | 1 << 16 | MFVI_TUNE_RP);
                 // small-map forward (conv_small.hip): one stage, the block's whole reduction in LDS
                 if (which <= 1 && o.g.ks == 3 && o.g.stride == 1 && o.g.W <= 16) cands.push_back(1 | MFVI_TUNE_SM);
+                // one-stage 1x1 kernel (conv_1x1.hip): the `up` 1x1 layers of 32 ... 128 channels; same tune bit
+                if (which <= 1 && o.g.ks == 1 && o.g.stride == 1 && (o.g.Cin & 15) == 0 && (o.g.Cout & 15) == 0 && o.g.Cin <= 128 && o.g.Cout <= 128
+                    && (((long long)o.g.H * o.g.W) & 63) == 0) cands.push_back(1 | MFVI_TUNE_SM);
                 // bf16x6 forward (conv_x6.hip): output fragments per block, 8 output rows per block
                 if (which == 0 && o.x6w_off >= 0) for (int mf : {1, 2}) for (int T = 1; T <= 16; T *= 2) cands.push_back(mf | 8 << 8 | T << 16 | MFVI_TUNE_X6);
                 // bf16x6 backward-data with the fold (conv_bwd_x6.hip): strips per block; rows per strip follow the output-channel count
