@@ -7,13 +7,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmfvi_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_bwd_x6.hip", "conv_small.hip", "conv_1x1.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
+SOURCES = ["conv_fwd.hip", "conv_bwd_data.hip", "conv_bwd_weight.hip", "conv_mfma.hip", "conv_rp.hip", "conv_x6.hip", "conv_bwd_x6.hip", "conv_bwd_x6s.hip", "conv_small.hip", "conv_1x1.hip", "conv_bww_mfma.hip", "conv_bww_x6.hip", "elementwise.hip", "losses.hip", "radon.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras.  conv_bwd_x6: no SLP vectorisation — packed fp32 instructions (v_pk_add / v_pk_fma) beside a matrix stream cost more issue time
 # than the scalar ones they replace (MI355X_MICROARCH.md; measured on this kernel: 68->32 @128^2 88.0 -> 78.8 us); the explicit pairs of the
 # bf16 split (common.h) stay packed
 # (the other two bf16x6 kernels: 1-5 % on the same A/B — backward-weight 36->16 85.6 -> 81.5 us, forward 132->64 59.5 -> 58.6)
-FILE_FLAGS = {"conv_bwd_x6.hip": ["-fno-slp-vectorize"], "conv_bww_x6.hip": ["-fno-slp-vectorize"], "conv_x6.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"conv_bwd_x6.hip": ["-fno-slp-vectorize"], "conv_bwd_x6s.hip": ["-fno-slp-vectorize"], "conv_bww_x6.hip": ["-fno-slp-vectorize"], "conv_x6.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -422,9 +422,13 @@ int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long 
 extern thread_local float* mfvi_tl_x6bw;
 extern thread_local bool mfvi_tl_x6bw_ready;
 long long x6_bwd_scratch_floats(const ConvGeom& g, int n_samples);
-struct X6BSplitEntry { long long w_off, dst_off; int CI, CO, NF, NG, k16, units, first_block, pad; };
+struct X6BSplitEntry { long long w_off, dst_off; int CI, CO, NF, NG, k16, units, first_block, rem_units; };      // rem_units: the (ky, c) operand of the last 4 input channels (conv_bwd_x6s.hip), behind the regular units
 bool x6b_split_entry(const ConvGeom& g, long long dst_off, X6BSplitEntry* e);
 int launch_x6b_split_all(const X6BSplitEntry* table_dev, int n_entries, int n_blocks, const float* w, long long wstride, int n_k, float* arena, hipStream_t st);
+// strip-resident form for 32 (+4) -> 16 layers (conv_bwd_x6s.hip; bit 16 of the bf16x6 backward-data tiling); -3: shape not served
+bool x6s_shape_ok(const ConvGeom& g);
+int launch_conv_bwd_data_x6s(const GView& gy, const ConvGeom& g, const unsigned* wsp, long long wsp_stride_u4, int rem_off_u4, int T, int n_samples,
+                             hipStream_t st, const FoldFuse& fuse);
 int launch_conv_bwd_data_x6(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int tune, int n_samples, hipStream_t st, const FoldFuse& fuse);
 // One launch per pass: W[k][j] = mu[j] + softplus(rho[j]) * eps_k[j] for the weights and biases of every layer in the table.
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };

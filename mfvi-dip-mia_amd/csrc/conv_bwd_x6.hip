@@ -116,16 +116,28 @@ struct X6BArgs {
 // destination (16-byte units): (((f * NG + grp) * 9 + tap) * NV + v) * 64 + g4 * 16 + n
 __device__ __forceinline__ void x6b_split_body(const X6BSplitEntry& E, int u, int k, const float* w, long long wstride, float* arena)
 {
-    if (u >= E.units) return;
-    const int g4 = u & 3, n = (u >> 2) & 15, r = u >> 6, tap = r % 9, fg = r / 9, grp = fg % E.NG, f = fg / E.NG;
+    if (u >= E.units + E.rem_units) return;
     const float* __restrict__ ww = w + (long long)k * wstride + E.w_off;
+    const long long sample_u4 = (long long)(E.units + E.rem_units) * (E.k16 ? 2 : 3);       // 16-byte units per sample
+    if (u >= E.units) {
+        // the last 4 input channels as ONE operand per kx (conv_bwd_x6s.hip): column n = (tap row ky, channel c), k-octets as the 16-channel form
+        const int uu = u - E.units, ln = uu & 63, kx = uu >> 6, g4 = ln >> 4, n = ln & 15, ky = n >> 2, ci = 32 + (n & 3), co0 = 8 * (g4 & 1);
+        float e8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e8[j] = ky < 3 ? ww[((long long)(co0 + j) * E.CI + ci) * 9 + ky * 3 + kx] : 0.f;
+        u32x4 h, m, l; split8(e8, h, m, l);
+        u32x4* d = reinterpret_cast<u32x4*>(arena + E.dst_off) + (long long)k * sample_u4 + (long long)E.units * 2 + (kx * 2) * 64 + ln;
+        d[0] = g4 < 2 ? h : m; d[64] = g4 < 2 ? l : h;
+        return;
+    }
+    const int g4 = u & 3, n = (u >> 2) & 15, r = u >> 6, tap = r % 9, fg = r / 9, grp = fg % E.NG, f = fg / E.NG;
     const int ci = 16 * f + n, co0 = 32 * grp + 8 * (E.k16 ? (g4 & 1) : g4);
     float e8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) e8[j] = ci < E.CI ? ww[((long long)(co0 + j) * E.CI + ci) * 9 + tap] : 0.f;
     u32x4 h, m, l; split8(e8, h, m, l);
     const int NV = E.k16 ? 2 : 3;
-    u32x4* d = reinterpret_cast<u32x4*>(arena + E.dst_off) + (long long)k * ((long long)E.units * NV) + ((long long)r * NV) * 64 + g4 * 16 + n;      // lane order (lane = 16 g4 + n): the wave's read of a unit is 1 KB of consecutive words, conflict-free
+    u32x4* d = reinterpret_cast<u32x4*>(arena + E.dst_off) + (long long)k * sample_u4 + ((long long)r * NV) * 64 + g4 * 16 + n;      // lane order (lane = 16 g4 + n): the wave's read of a unit is 1 KB of consecutive words, conflict-free
     if (E.k16) { d[0] = g4 < 2 ? h : m; d[64] = g4 < 2 ? l : h; }      // [w_h | w_m], [w_l | w_h]
     else { d[0] = h; d[64] = m; d[128] = l; }
 }
@@ -626,14 +638,14 @@ long long x6_bwd_scratch_floats(const ConvGeom& g, int n_samples)
 {
     if (!x6b_shape_ok(g)) return 0;
     const int NF = (g.Cin + 15) / 16, NG = g.Cout == 64 ? 2 : 1, NV = g.Cout == 16 ? 2 : 3;
-    return (long long)NF * NG * 9 * NV * 256 * n_samples;
+    return ((long long)NF * NG * 9 * NV * 256 + (g.Cout == 16 && g.Cin == 36 ? 192 * NV * 4 : 0)) * n_samples;
 }
 
 bool x6b_split_entry(const ConvGeom& g, long long dst_off, X6BSplitEntry* e)
 {
     if (!x6b_shape_ok(g)) return false;
     e->w_off = g.w_off; e->dst_off = dst_off; e->CI = g.Cin; e->CO = g.Cout; e->NF = (g.Cin + 15) / 16; e->NG = g.Cout == 64 ? 2 : 1;
-    e->k16 = g.Cout == 16 ? 1 : 0; e->units = e->NF * e->NG * 9 * 64; e->first_block = 0; e->pad = 0;
+    e->k16 = g.Cout == 16 ? 1 : 0; e->units = e->NF * e->NG * 9 * 64; e->first_block = 0; e->rem_units = (g.Cout == 16 && g.Cin == 36) ? 192 : 0;
     return true;
 }
 
@@ -661,11 +673,13 @@ int launch_conv_bwd_data_x6(const GView& gy, const ConvGeom& g, const float* w, 
     const int n_k = wstride ? n_samples : 1;
     if (!mfvi_tl_x6bw_ready) {      // no pass-wide split ran: this layer's own launch (dst_off 0: `scratch` is the layer's region)
         E.dst_off = 0;
-        hipLaunchKernelGGL(x6b_split_one_kernel, dim3((E.units + 255) / 256, n_k), dim3(256), 0, st, E, w, wstride, scratch);
+        hipLaunchKernelGGL(x6b_split_one_kernel, dim3((E.units + E.rem_units + 255) / 256, n_k), dim3(256), 0, st, E, w, wstride, scratch);
     }
     X6BArgs A{};
     A.gin = gy; A.xin = fuse.x; A.g = g;
-    A.wsp = reinterpret_cast<const unsigned*>(scratch); A.wsp_stride_u4 = wstride ? (long long)E.units * NV : 0;
+    A.wsp = reinterpret_cast<const unsigned*>(scratch); A.wsp_stride_u4 = wstride ? (long long)(E.units + E.rem_units) * NV : 0;
+    if (tune & (1 << 16))      // strip-resident form (conv_bwd_x6s.hip)
+        return launch_conv_bwd_data_x6s(gy, g, A.wsp, A.wsp_stride_u4, E.units * NV, T, n_samples, st, fuse);
     A.fga = fuse.ga; A.fga_sstride = fuse.ga_sstride; A.fbsums = fuse.bsums;
     A.NF = E.NF; A.bands = g.W / 64; A.strips = g.H / sr; A.tpb = T;
     A.nx = A.bands * ((A.strips + T - 1) / T); A.nz = n_samples;

@@ -756,7 +756,7 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         for (auto& o : plan->ops)
             if (o.d.type == MFVI_OP_CONV && o.x6bw_off >= 0 && (o.g.tune[1] & MFVI_TUNE_X6) && ((o.d.in0 != plan->input) || dz != nullptr)) {
                 X6BSplitEntry e; if (!x6b_split_entry(o.g, o.x6bw_off, &e)) continue;
-                e.first_block = nb; nb += (e.units + 255) / 256; tab.push_back(e);
+                e.first_block = nb; nb += (e.units + e.rem_units + 255) / 256; tab.push_back(e);
             }
         if (!tab.empty()) {
             hipError_t e = hipSuccess;
@@ -1171,6 +1171,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                 if (which == 0 && o.x6w_off >= 0) for (int mf : {1, 2}) for (int T = 1; T <= 16; T *= 2) cands.push_back(mf | 8 << 8 | T << 16 | MFVI_TUNE_X6);
                 // bf16x6 backward-data with the fold (conv_bwd_x6.hip): strips per block; rows per strip follow the output-channel count
                 if (which == 1 && o.x6bw_off >= 0) for (int T : {1, 2, 4, 8, 16, 32}) cands.push_back(T | (o.g.Cout == 16 ? 8 : o.g.Cout == 32 ? 4 : 2) << 8 | MFVI_TUNE_X6);
+                if (which == 1 && o.x6bw_off >= 0 && x6s_shape_ok(o.g)) for (int T : {2, 4, 8, 16, 32}) cands.push_back(T | 8 << 8 | 1 << 16 | MFVI_TUNE_X6);      // strip-resident form (conv_bwd_x6s.hip)
             }
             else {
                 for (int nb = 1; nb <= 3; ++nb) for (int nw : {4, 8, 9}) for (int tb = 1; tb <= 8; tb *= 2) cands.push_back(nb | nw << 8 | tb << 16);

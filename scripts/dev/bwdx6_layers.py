@@ -67,6 +67,14 @@ for cin, cout, hw in specs:
                 print("%d->%d @%d bwd_data bf16x6 T=%d: fell back to family %d" % (cin, cout, hw, T, lib.mfvi_plan_last_kernel(plan.handle, op, 1)), flush=True); continue
             print("%d->%d @%d bwd_data bf16x6 sr=%d T=%2d: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak, %.3f of 2.5 PF / 6) %5.0f GB/s incl. fold" % (
                 cin, cout, hw, sr, T, us, tf(us), tf(us) / 157.3, tf(us) / (2500.0 / 6), byts / us / 1e3), flush=True)
+    if sr == 8 and cin in (32, 36):      # strip-resident form (conv_bwd_x6s.hip)
+        for T in (2, 4, 8, 16, 32):
+            M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 1, T | sr << 8 | 1 << 16 | 1 << 25))
+            us = measure(plan, op, bufs, 2)
+            if lib.mfvi_plan_last_kernel(plan.handle, op, 1) != 3:
+                print("strip-resident T=%d: fell back" % T); continue
+            print("%d->%d @%d bwd_data bf16x6 strip-resident T=%2d: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak, %.3f of 2.5 PF / 6) %5.0f GB/s incl. fold" % (
+                cin, cout, hw, T, us, tf(us), tf(us) / 157.3, tf(us) / (2500.0 / 6), byts / us / 1e3), flush=True)
     for mf, r, T, rem in (() if only else ((1, 1, 8, 1), (2, 1, 4, 1), (2, 1, 2, 1), (1, 1, 4, 0), (2, 1, 4, 0))):
         M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 1, mf | r << 8 | rem << 12 | T << 16 | 1 << 24))
         try:

@@ -54,6 +54,50 @@ def test_x6_backward_data_against_fp32_tilings(M, shape):
             assert relerr(a, b) < 2e-5, (name, T)
 
 
+# strip-resident form (csrc/conv_bwd_x6s.hip, bit 16 of the tiling): 36 -> 16 and 32 -> 16; one strip (first AND last: both row adjoints in one
+# sweep), two, four strips; one band (both column adjoints), two, three bands
+S_SHAPES = [(36, 16, 8, 64), (36, 16, 16, 64), (36, 16, 32, 128), (36, 16, 16, 192), (32, 16, 16, 64), (32, 16, 24, 128)]
+
+
+@pytest.mark.parametrize("shape", S_SHAPES)
+@pytest.mark.parametrize("act", [True, False])
+def test_x6_strip_resident_form_against_fp32_tilings(M, shape, act):
+    """Weights resident in registers, one sweep per strip, the last 4 input channels as ONE (tap row, channel) operand whose columns are
+    shifted onto their output rows: every gradient of the plan against the round-2 rectangular tiling; the layer's input with and without
+    an activation behind its BatchNorm (the net's 36-channel concat tensor has none); strips per block that do not divide the strips."""
+    cin, cout, H, W = shape
+    n, seed = 2, 95
+    P = M.Program()
+    zin = P.tensor(cin, H, W)
+    x = P.tensor(cin, H, W); P.conv(zin, x, 1, 1); P.set_bn(x, act=act)
+    y = P.tensor(cout, H, W); P.conv(x, y, 3, 1); P.set_bn(y, act=True)
+    out = P.tensor(2, H, W); P.conv(y, out, 1, 1)
+    plan = P.compile(zin, out, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    assert lib.mfvi_plan_last_kernel(plan.handle, 1, 1) in (1, 2)
+    for T in (1, 2, 3, 16):
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, x6_tune(cout, T) | 1 << 16))
+        got = _run_plan(plan, P, seed, n, z, dout)
+        assert lib.mfvi_plan_last_kernel(plan.handle, 1, 1) == 3, "the bf16x6 backward-data kernel did not run"
+        assert relerr(got[0], ref[0]) == 0.0, ("out", T)
+        for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+            assert relerr(a, b) < 2e-5, (name, T)
+
+
+def test_x6_strip_resident_form_refuses_other_shapes(M):
+    """68 -> 32 with bit 16 set: the tiling is not valid for the shape (-3), the plan runs that launch on the generic kernel."""
+    P, plan, zin, out = _conv_bn_plan(M, 68, 32, 8, 64, 1)
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, x6_tune(32, 1) | 1 << 16))
+    z = dev(O.normal_fill(3, 2, 2, 0, 0, 68 * 8 * 64).reshape(68, 8, 64)); dout = dev(O.normal_fill(3, 2, 3, 0, 0, 2 * 8 * 64).reshape(1, 2, 8, 64))
+    _run_plan(plan, P, 3, 1, z, dout)
+    assert lib.mfvi_plan_last_kernel(plan.handle, 1, 1) == 0
+
+
 def test_x6_backward_data_without_a_weight_draw_falls_back(M):
     """w = mu (sample_weights = 0, the siblings' path): no weight-piece scratch is handed over, the tiling stays set and the layer runs on
     its fp32 default — same gradients."""
