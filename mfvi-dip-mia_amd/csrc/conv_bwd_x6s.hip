@@ -236,12 +236,12 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6s_kernel(X6SArgs A)
         // activation variant) makes it wait for vmcnt(0) at the next consumer — the fold of a strip then waited for the dy rows requested
         // right in front of it, one exposed memory round trip per strip (timing-only build without the raw-x loads: 113 -> 87 us).
         const bool xact = (A.xin.act & 1) != 0; const float xslope = A.xin.slope;
-        const float* __restrict__ xq = fuse_sums ? A.xin.data + (long long)k * A.xin.sstride : nullptr;
+        const float* __restrict__ xq = A.xin.data + (long long)k * A.xin.sstride;
         float* __restrict__ gout = A.fga + (long long)k * A.fga_sstride;
         const int fchl = t >> 4, fv = t & 15;               // full tiles: thread = (channel of the fragment, float4 column), SR items = tile rows
         const int rg = lane >> 4;                           // 4-channel tile: wave = channel 32 + wv, lane = (row group, float4 column), rows rg and rg + 4
         auto run = [&](auto sums_c, auto act_c) {
-            constexpr bool SUMS = decltype(sums_c)::value, ACT = decltype(act_c)::value;
+            constexpr bool SUMS = decltype(sums_c)::value;
             float ga_[3][8], y_[3][8];
             float4 xpre[SR] = {};                           // raw x of the fold, rolling: item j of the next tile is requested when item j of the current one is consumed
             // byte offset of (channel ch, image row r0, this thread's float4 column)
@@ -260,12 +260,15 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6s_kernel(X6SArgs A)
                 float dd[4] = {d4.x, d4.y, d4.z, d4.w};
                 if constexpr (SUMS) {
                     const float yy[4] = {x4.x, x4.y, x4.z, x4.w};
+                    float ymv[4];
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) {
-                        const float ym = yy[l] - cf.mean;
-                        if constexpr (ACT) { const float vv = __builtin_fmaf(ym, cf.scale, cf.beta); dd[l] *= (vv > 0.f) ? 1.f : xslope; }
-                        fs += dd[l]; fx = __builtin_fmaf(dd[l], ym, fx);      // (views without an activation — the concat tensors of the skip() nets — three operations per element)
+                    for (int l = 0; l < 4; ++l) ymv[l] = yy[l] - cf.mean;
+                    if (xact) {     // wave-uniform branch around vector arithmetic ONLY (no memory operation inside: the waitcnt bookkeeping stays exact)
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) { const float vv = __builtin_fmaf(ymv[l], cf.scale, cf.beta); dd[l] *= (vv > 0.f) ? 1.f : xslope; }
                     }
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) { fs += dd[l]; fx = __builtin_fmaf(dd[l], ymv[l], fx); }      // (views without an activation — the concat tensors of the skip() nets — three operations per element)
                 }
                 return make_float4(dd[0], dd[1], dd[2], dd[3]);
             };
@@ -376,9 +379,9 @@ __global__ __launch_bounds__(512, 2) void conv_bwd_x6s_kernel(X6SArgs A)
             { XS_T(sf1); XS_ACC(21, sf1 - sf0); if (t == 0) for (int i = 10; i < 24; ++i) atomicAdd(&g_x6s_prof[i], prof[i]); }
 #endif
         };
-        if (!fuse_sums) run(std::false_type{}, std::false_type{});
-        else if (xact) run(std::true_type{}, std::true_type{});
-        else run(std::true_type{}, std::false_type{});
+        // ONE variant: the raw x is loaded and the sums are formed even when the input carries no BatchNorm (never on this path in skip():
+        // identity constants, the sums are not written out); LeakyReLU' is a wave-uniform branch around vector arithmetic only
+        run(std::true_type{}, std::true_type{});
     } else {
         // ======================= matrix waves: wave = (fragment mf, pixel half) =======================
         const bool rbd = c0 + 64 == W;
