@@ -376,14 +376,18 @@ __global__ __launch_bounds__(256) void concat_up_fwd_tiled_kernel(TView a, int h
 //   channels of B  : the hi-res window rows 2*m0-1 .. 2*m0+2*CB_TH, cols 2*n0-1 .. 2*n0+2*CB_TW of dy is staged ONCE
 //                    (coalesced float2 loads), split into even/odd column planes so the stride-2 taps of the bilinear
 //                    adjoint read LDS conflict-free; each thread then gathers its 4x4 taps from LDS.
-constexpr int CB_TH = 16, CB_TW = 64;
-constexpr int CB_ROWS = 2 * CB_TH + 2, CB_PITCH = CB_TW + 1;      // staged rows; entries per even / odd plane row
-
+// Tile shapes (round 4): 16 x 64 low-res pixels for maps at least 48 wide; 32 x 32 and 16 x 16 for the 32-, 16- and 8-wide low-res maps of the
+// deeper scales, where a 64-wide tile left half to seven eighths of every block's lanes without a pixel (concat_bwd of the 64^2 / 32^2 /
+// 16^2 scales: 39 / 24 / 21 us for 73 / 18 / 5 MB).  256 threads, CB_TH * CB_TW / 256 outputs per thread.
+template <int CB_TH, int CB_TW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void concat_up_bwd_kernel(GView gc, TView a, int has_a, float* __restrict__ ga_a,
                                                             long long ga_a_sstride, double* __restrict__ bsums_a,
                                                             TView b, float* __restrict__ ga_b, long long ga_b_sstride,
                                                             double* __restrict__ bsums_b, int tiles_x, int nearest, int pairs)
 {
+    constexpr int CB_ROWS = 2 * CB_TH + 2, CB_PITCH = CB_TW + 1;      // staged rows; entries per even / odd plane row
+    constexpr int RSTEP = 256 / CB_TW, NQ = CB_TH / RSTEP;            // a thread's outputs: rows t / CB_TW + RSTEP * q of column t % CB_TW
+    static_assert(256 % CB_TW == 0 && CB_TH % RSTEP == 0 && NQ >= 1, "tile geometry");
     __shared__ ChanFwd s_ch;
     __shared__ ChanBwd s_cg;
     __shared__ double s_red[8];
@@ -393,9 +397,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     const bool from_a = c < Ca;
     const int H = gc.H, W = gc.W;
     const long long HW = (long long)H * W;
-    if (t == 0) { s_ch = from_a ? chan_fwd(a, k, c) : chan_fwd(b, k, c - Ca); s_cg = chan_bwd(gc, k, c); }
-    __syncthreads();
-    const ChanFwd ch = s_ch; const ChanBwd cg = s_cg;
+    // channel constants (fp64 divisions and square roots) by one lane of two different waves, needed only behind the batch of loads below
+    if (t == 0) s_ch = from_a ? chan_fwd(a, k, c) : chan_fwd(b, k, c - Ca);
+    if (t == 64) s_cg = chan_bwd(gc, k, c);
     const float* __restrict__ gap = gc.ga + (long long)k * gc.gstride + (long long)c * HW;
     const float* __restrict__ ycp = gc.y + (long long)k * gc.ystride + (long long)c * HW;
     const bool cat_bn = gc.stats != nullptr;
@@ -434,6 +438,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
                 if (ok && q + 1 >= W) pixs[j] = -2 - pix;      // only the first element exists
             }
         }
+        __syncthreads();
+        const ChanFwd ch = s_ch; const ChanBwd cg = s_cg;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             if (pixs[j] == -1) continue;
@@ -482,13 +488,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             }
         }
         // raw destination values of this thread's outputs (LeakyReLU' and x-hat of the BN-backward sums), requested with the batch above
-        const int nl = t & 63, n = n0 + nl;
-        float ydv[CB_TH / 4];
+        const int nl = t % CB_TW, n = n0 + nl;
+        float ydv[NQ];
 #pragma unroll
-        for (int q = 0; q < CB_TH / 4; ++q) {
-            const int m = m0 + (t >> 6) + 4 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int m = m0 + t / CB_TW + RSTEP * q;
             ydv[q] = (dst_bn && m < dst.H && n < dst.W) ? yd[m * dst.W + n] : 0.f;
         }
+        __syncthreads();
+        const ChanFwd ch = s_ch; const ChanBwd cg = s_cg;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int i = t + 256 * j, lr = i / SLOTS, sl = i - lr * SLOTS;
@@ -505,8 +513,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
         //      .25 .75 .75 .25; at the borders the clamped taps collapse: row 0 gets 1.0 from hi-res row 0 and the last row 1.0
         //      from the last hi-res row (columns alike).
 #pragma unroll
-        for (int qq = 0; qq < CB_TH / 4; ++qq) {
-            const int ml = (t >> 6) + 4 * qq;
+        for (int qq = 0; qq < NQ; ++qq) {
+            const int ml = t / CB_TW + RSTEP * qq;
             const int m = m0 + ml;
             if (m >= dst.H || n >= dst.W) continue;
             float wy[4], wx[4];
@@ -762,11 +770,16 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
     const auto al8 = [](const void* q) { return ((uintptr_t)q & 7) == 0; };
     const int pairs = !((gc.W & 1) || ((gc.gstride | gc.ystride) & 1) || !al8(gc.ga) || (gc.y && !al8(gc.y)) ||
                         (a && (((a->sstride | ga_a_sstride) & 1) || !al8(a->data) || !al8(ga_a))));
-    const int tiles_x = (b.W + CB_TW - 1) / CB_TW, tiles_y = (b.H + CB_TH - 1) / CB_TH;
-    dim3 grid((unsigned)(tiles_x * tiles_y), Ct, n_samples);
     TView av = a ? *a : b;
-    mfvi_launch(concat_up_bwd_kernel, grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b,
-                       ga_b_sstride, bsums_b, tiles_x, nearest, pairs);
+    static const int force = [] { const char* e = getenv("MFVI_CONCAT_BWD_TILE"); return e ? atoi(e) : 0; }();      // 64 / 32 / 16: A/B of the tile shapes
+    const int tw = force ? force : (b.W >= 48 ? 64 : b.W >= 24 ? 32 : 16);
+#define CB_GO(TH_, TW_) { \
+        const int tiles_x = (b.W + TW_ - 1) / TW_, tiles_y = (b.H + TH_ - 1) / TH_; \
+        dim3 grid((unsigned)(tiles_x * tiles_y), Ct, n_samples); \
+        mfvi_launch((concat_up_bwd_kernel<TH_, TW_>), grid, dim3(256), 0, st, gc, av, a ? 1 : 0, ga_a, ga_a_sstride, bsums_a, b, ga_b, \
+                    ga_b_sstride, bsums_b, tiles_x, nearest, pairs); }
+    if (tw == 64) CB_GO(16, 64) else if (tw == 32) CB_GO(32, 32) else CB_GO(16, 16)
+#undef CB_GO
     return (int)hipGetLastError();
 }
 
