@@ -461,6 +461,8 @@ struct FoldSrcs { FoldSrc s[MAX_FOLD_SRC]; int n; };
 // ga_X = act'(X) * fold(sum of sources); accumulates BN-backward sums of X.
 int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga, long long ga_sstride, double* bsums,
                        int n_samples, hipStream_t st);
+int launch_finalize_dx_inline1x1(const FoldSrc& s0, const GView& g1, const float* w1, long long w1_sstride, int cs1, const TView& x, float* ga,
+                                 long long ga_sstride, double* bsums, int n_samples, hipStream_t st);
 // ---- local reparameterisation (LRTLayer.forward, BayTorch/modules/reparam_layers.py:59-72) around two ordinary convolutions ----
 // sig2[j] = softplus(rho[j])^2 for j in [0, n): the weights / bias of the variance convolution
 int launch_lrt_sigma2(const float* rho, long long n, float* sig2, hipStream_t st);

@@ -156,6 +156,89 @@ __global__ __launch_bounds__(256) void finalize_dx_vec_kernel(FoldSrc s0, FoldSr
     }
 }
 
+// finalize_dx with ONE padded source and the backward-data of a narrow 1x1 consumer formed in place (round 4): a tensor of
+// the down path feeds the stride-2 3x3 convolution of its scale and the 4-channel 1x1 skip convolution (models/skip.py:60-66).  The skip
+// branch's gradient wrt x is dx[c][p] = sum_j W_k[j][c] * dy_j[p] over CS <= 8 output channels — 4 multiply-adds per element — and used to be
+// a launch of its own (8-12 us, a padded-gradient scratch written and read back).  Here dy_j is formed on load (BN-backward of the skip
+// branch's BatchNorm) from the CS small planes every channel block of the grid re-reads through L2.  Two float4 groups per thread.
+constexpr int V1_GROUPS = 2;
+template <int V1_MAXC>      // 4 or 8: channels of the 1x1 consumer held in registers (cs1 <= V1_MAXC)
+__global__ __launch_bounds__(256) void finalize_dx_vec1_kernel(FoldSrc s0, GView g1, const float* __restrict__ w1, long long w1_sstride, int cs1, TView x,
+                                                               float* __restrict__ ga, long long ga_sstride, double* __restrict__ bsums)
+{
+    __shared__ ChanFwd s_ch;
+    __shared__ ChanBwd s_cb[V1_MAXC];
+    __shared__ float s_w1[V1_MAXC];
+    __shared__ double s_red[8];
+    const int t = threadIdx.x, k = blockIdx.z, c = blockIdx.y;
+    const int H = x.H, W = x.W, W4 = W >> 2;
+    const long long HW = (long long)H * W;
+    const int n_groups = H * W4;
+    if (t == 0) s_ch = chan_fwd(x, k, c);
+    if (t >= 64 && t < 64 + cs1) { s_cb[t - 64] = chan_bwd(g1, k, t - 64); s_w1[t - 64] = w1[(long long)k * w1_sstride + (long long)(t - 64) * x.C + c]; }
+    const bool has_bn = x.stats != nullptr, bn1 = g1.stats != nullptr;
+    const float* __restrict__ yx = x.data + (long long)k * x.sstride + (long long)c * HW;
+    float* __restrict__ gout = ga + (long long)k * ga_sstride + (long long)c * HW;
+    const float* __restrict__ ga1 = g1.ga + (long long)k * g1.gstride;
+    const float* __restrict__ y1 = bn1 ? g1.y + (long long)k * g1.ystride : ga1;      // (no BatchNorm behind the skip convolution: the loads still run, against qc = 0)
+    const int p = s0.pad, Hp = H + 2 * p, Wp = W + 2 * p;
+    const float* __restrict__ base = s0.d + (long long)k * s0.sstride + (long long)c * Hp * Wp;
+    float4 d[V1_GROUPS], yv[V1_GROUPS], g4[V1_GROUPS][V1_MAXC], y4[V1_GROUPS][V1_MAXC];
+#pragma unroll
+    for (int it = 0; it < V1_GROUPS; ++it) {
+        const int gi = min((int)(blockIdx.x * V1_GROUPS + it) * 256 + t, n_groups - 1);      // (clamped: every load unconditional; lanes past the end do not store)
+        const int r = gi / W4, q = (gi - r * W4) * 4;
+        float4 v = fold_row4(base, r + p, q, W, Wp, p);
+        if (p) {
+            if (r == 1) { const float4 u = fold_row4(base, 0, q, W, Wp, p); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            if (r == H - 2) { const float4 u = fold_row4(base, H + 1, q, W, Wp, p); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        }
+        d[it] = v;
+        yv[it] = *reinterpret_cast<const float4*>(yx + (long long)gi * 4);
+#pragma unroll
+        for (int j = 0; j < V1_MAXC; ++j) {
+            const int jj = min(j, cs1 - 1);
+            g4[it][j] = *reinterpret_cast<const float4*>(ga1 + (long long)jj * HW + (long long)gi * 4);
+            y4[it][j] = *reinterpret_cast<const float4*>(y1 + (long long)jj * HW + (long long)gi * 4);
+        }
+    }
+    __syncthreads();
+    const ChanFwd ch = s_ch;
+    double sg = 0.0, sgx = 0.0;
+#pragma unroll
+    for (int it = 0; it < V1_GROUPS; ++it) {
+        const int gi = (blockIdx.x * V1_GROUPS + it) * 256 + t;
+        float dd[4] = {d[it].x, d[it].y, d[it].z, d[it].w};
+#pragma unroll
+        for (int j = 0; j < V1_MAXC; ++j) {
+            if (j < cs1) {
+                const ChanBwd cb = s_cb[j]; const float wj = s_w1[j];
+                dd[0] = __builtin_fmaf(wj, apply_bwd(cb, g4[it][j].x, y4[it][j].x), dd[0]); dd[1] = __builtin_fmaf(wj, apply_bwd(cb, g4[it][j].y, y4[it][j].y), dd[1]);
+                dd[2] = __builtin_fmaf(wj, apply_bwd(cb, g4[it][j].z, y4[it][j].z), dd[2]); dd[3] = __builtin_fmaf(wj, apply_bwd(cb, g4[it][j].w, y4[it][j].w), dd[3]);
+            }
+        }
+        if (gi >= n_groups) continue;
+        if (has_bn) {
+            const float yy[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = __builtin_fmaf(yy[j] - ch.mean, ch.scale, ch.beta);
+                if ((x.act & 1) && !(v > 0.f)) dd[j] *= x.slope;
+                sg += (double)dd[j]; sgx += (double)dd[j] * (double)((yy[j] - ch.mean) * ch.rstd);
+            }
+        }
+        *reinterpret_cast<float4*>(gout + (long long)gi * 4) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    }
+    if (has_bn) {
+        const double a = block_sum_d(sg, s_red);
+        const double b = block_sum_d(sgx, s_red);
+        if (t == 0) {
+            double* o = bsums + ((long long)k * x.C + c) * 2;
+            atomicAdd(o, a); atomicAdd(o + 1, b);
+        }
+    }
+}
+
 // bilinear x2, align_corners=False: src = (dst+0.5)/2-0.5 clamped at 0, i1 = min(i0+1, n-1)
 __device__ __forceinline__ void up_coef(int d, int n, int& i0, int& i1, float& l1)
 {
@@ -704,6 +787,20 @@ int launch_finalize_dx(const FoldSrc* srcs, int n_src, const TView& x, float* ga
     FoldSrcs S; S.n = n_src;
     for (int i = 0; i < MAX_FOLD_SRC; ++i) S.s[i] = srcs[i < n_src ? i : 0];
     mfvi_launch(finalize_dx_kernel, grid, dim3(256), 0, st, S, x, ga, ga_sstride, bsums);
+    return (int)hipGetLastError();
+}
+
+// One padded source + the backward-data of a 1x1 consumer with cs1 <= 8 output channels in place (finalize_dx_vec1_kernel).  -2: shape not served
+int launch_finalize_dx_inline1x1(const FoldSrc& s0, const GView& g1, const float* w1, long long w1_sstride, int cs1, const TView& x, float* ga,
+                                 long long ga_sstride, double* bsums, int n_samples, hipStream_t st)
+{
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (cs1 < 1 || cs1 > 8 || s0.mul2v || s0.pad > 1 || (x.W & 3) || x.H < 2 || ((x.sstride | ga_sstride | g1.gstride) & 3) || !al16(x.data) || !al16(ga) ||
+        !al16(g1.ga) || (g1.stats && (!al16(g1.y) || (g1.ystride & 3))) || g1.H != x.H || g1.W != x.W) return -2;
+    const long long HW = (long long)x.H * x.W;
+    dim3 grid((unsigned)((HW / 4 + 256 * V1_GROUPS - 1) / (256 * V1_GROUPS)), x.C, n_samples);
+    if (cs1 <= 4) mfvi_launch(finalize_dx_vec1_kernel<4>, grid, dim3(256), 0, st, s0, g1, w1, w1_sstride, cs1, x, ga, ga_sstride, bsums);
+    else mfvi_launch(finalize_dx_vec1_kernel<8>, grid, dim3(256), 0, st, s0, g1, w1, w1_sstride, cs1, x, ga, ga_sstride, bsums);
     return (int)hipGetLastError();
 }
 

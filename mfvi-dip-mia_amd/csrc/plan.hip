@@ -392,11 +392,15 @@ int conv_bwd_data_plain(const GView& gy, const ConvGeom& g, const float* w_base,
 
 // Gradient wrt tensor `tid` once every consumer has written its padded input gradient: reflection-pad adjoint fold, sum over the
 // consumers (an LRT consumer contributes two sources, the variance branch with the factor 2 * view(x)), LeakyReLU', BN-backward sums.
-int fold_consumers(mfvi_plan* plan, const Ctx& c, int tid, const TView& xin, float* dz, int sample_weights, int op_index, int n_samples, hipStream_t st)
+// inline_op >= 0: that consumer (a narrow 1x1 convolution) wrote no padded gradient — its backward-data is formed inside the fold from its
+// output gradient gy1 and its weights w1 (launch_finalize_dx_inline1x1); -2 from there: the caller launches the consumer after all
+int fold_consumers(mfvi_plan* plan, const Ctx& c, int tid, const TView& xin, float* dz, int sample_weights, int op_index, int n_samples, hipStream_t st,
+                   int inline_op = -1, const GView* gy1 = nullptr, const float* w1 = nullptr, long long w1_sstride = 0)
 {
     const TensorInfo& x = plan->t[tid];
     FoldSrc srcs[MAX_FOLD_SRC]; int ns = 0;
     for (int ci : x.consumers) {
+        if (ci == inline_op) continue;
         const OpInfo& co = plan->ops[ci]; const int Pc = co.g.ks / 2;
         const long long per = (long long)co.g.Cin * (co.g.H + 2 * Pc) * (co.g.W + 2 * Pc);
         srcs[ns++] = FoldSrc{c.farena() + co.scratch_off, per, Pc, 0};
@@ -404,6 +408,11 @@ int fold_consumers(mfvi_plan* plan, const Ctx& c, int tid, const TView& xin, flo
     }
     float* ga = (tid == plan->input) ? dz : c.farena() + x.ga_off;
     ProfScope ps(plan, op_index, PASS_FINALIZE, st);
+    if (inline_op >= 0) {
+        if (ns != 1) return -2;
+        const OpInfo& io = plan->ops[inline_op];
+        return launch_finalize_dx_inline1x1(srcs[0], *gy1, w1 + io.g.w_off, w1_sstride, io.g.Cout, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
+    }
     return launch_finalize_dx(srcs, ns, xin, ga, x.numel, x.d.has_bn ? c.bsums() + x.stats_off : nullptr, n_samples, st);
 }
 
@@ -941,6 +950,20 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
                     if (r2 == 0) folded = true; else { armed_idx = -1; if (r2 != -2 && r2 != -3) rc = r2; }
                 }
                 const bool fold_here = x.consumers.front() == i;
+                // The tensor's other consumer has written its padded gradient and this one is a narrow 1x1 convolution (the 4-channel skip
+                // branch of a down-path tensor): no launch of its own — its backward-data is formed inside the fold (elementwise.hip,
+                // finalize_dx_vec1_kernel).  MFVI_FUSE_SKIP_BWD=0: the separate launch (A/B, parity cross-checks).
+                static const bool fuse_skip = [] { const char* e = getenv("MFVI_FUSE_SKIP_BWD"); return !(e && e[0] == '0'); }();
+                if (!rc && !folded && fold_here && fuse_skip && o.d.type == MFVI_OP_CONV && o.g.ks == 1 && o.g.stride == 1 && o.g.Cout <= 8 && x.consumers.size() == 2 &&
+                    plan->ops[x.consumers.back()].d.type == MFVI_OP_CONV && use_mfma() &&
+                    (presample ? (!(o.g.Cin & 3) && !(o.g.w_off & 3) && o.g.Cin <= MFVI_MAX_C) : (!sample_weights && mu != nullptr))) {      // (its weights are in the slab, or w = mu)
+                    ProfScope ps(plan, i, PASS_BWD_DATA, st);      // (booked on the op's backward-data slot: the fold now holds both)
+                    { const int ra = arm(i); if (ra) return ra; }
+                    const int r2 = fold_consumers(plan, c, o.d.in0, xin, dz, sample_weights, i, n_samples, st, i, &gy, wsrc, wstride);
+                    settle();
+                    if (r2 == 0) { folded = true; o.family[1] = 5; }
+                    else { armed_idx = -1; if (r2 != -2) rc = r2; }
+                }
                 if (!rc && !folded) {
                   ProfScope ps(plan, i, PASS_BWD_DATA, st);
                   if (!fold_here) { const int ra = arm(i); if (ra) return ra; }      // no fold behind it: this is the op's last launch on `st`
