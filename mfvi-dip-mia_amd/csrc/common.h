@@ -434,7 +434,7 @@ int launch_conv_bwd_data_x6(const GView& gy, const ConvGeom& g, const float* w, 
 struct SampleEntry { long long w_off, b_off; int n_w, n_b, layer_id, first_block; };
 // bf16: mu / rho point to bf16_t arrays; sample = 0 writes W = mu (RTLayer's eval branch) — callers then launch it for ONE sample
 int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const void* mu, const void* rho, RngKey key,
-                          int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16 = 0, int sample = 1);
+                          int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16 = 0, int sample = 1, double* zero = nullptr, long long n_zero = 0);      // zero: n_zero doubles cleared by the same launch
 // bf16 -> float32 expansion (the generic fp32 kernels of shapes the MFMA path does not serve read float32 mu / rho)
 int launch_expand_bf16(const void* src, long long n, float* dst, hipStream_t st);
 constexpr int SAMPLE_QUADS = 256;       // weight quads per block of the sampling kernel
@@ -450,9 +450,25 @@ int launch_conv_bwd_weight_x6(const TView& in, const GView& gy, const ConvGeom& 
                               int n_samples, hipStream_t st);
 struct GradFinEntry { long long w_off, b_off, part_off, stride; int n_w, n_b, strips, layer_id, first_block, pad; };
 // wsamp (optional): the sampled-weight slab of this pass, sample k at wsamp + k*wstride; then eps_k*softplus(rho) is read as W_k - mu
+struct BnGradEntry { long long bsums_off; long long bn_off; int C; int hw; };      // hw = H * W of the normalised tensor
+// BatchNorm parameter gradients of ONE table entry from the accumulated BN-backward sums: d gamma = sum ga * xhat, d beta = sum ga
+// (a block's worth of work: bn_param_grads_kernel, or an extra block of grad_finalize_kernel)
+__device__ __forceinline__ void bn_param_grads_entry(const BnGradEntry e, const double* __restrict__ bsums_base, int n_samples, float* __restrict__ dbn)
+{
+    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+        double sb = 0, sg = 0;
+        for (int k = 0; k < n_samples; ++k) {
+            const double* s = bsums_base + e.bsums_off + ((long long)k * e.C + c) * 2;
+            sb += s[0]; sg += s[1];
+        }
+        dbn[e.bn_off + c] += (float)sg;            // d gamma = sum ga * xhat
+        dbn[e.bn_off + e.C + c] += (float)sb;      // d beta  = sum ga
+    }
+}
+// bn_table / n_bn / bsums_base / dbn (optional): the BatchNorm parameter gradients as n_bn extra blocks of the same launch
 int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const void* rho, RngKey key,
                          int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const void* mu,
-                         hipStream_t st, int bf16 = 0);
+                         hipStream_t st, int bf16 = 0, const BnGradEntry* bn_table = nullptr, int n_bn = 0, const double* bsums_base = nullptr, float* dbn = nullptr);
 constexpr int GRAD_FIN_QUADS = 64;      // weight quads per block of the finalize kernel
 // mul2v: the source is the gradient wrt view(X)**2 (variance convolution of an LRT layer): it enters with the factor 2 * view(X)
 struct FoldSrc { const float* d; long long sstride; int pad; int mul2v; };
@@ -480,7 +496,6 @@ int launch_concat_up_bwd(const GView& gc, const TView* a, float* ga_a, long long
 // Dropout2d factors of one forward: arena[e.drop_off + k*C + c] for every entry, sample k, channel c (RNG domain 5, stream layer_id)
 struct DropEntry { long long drop_off; int C, layer_id; float p; int pad; };
 int launch_dropout_masks(const DropEntry* table_dev, int n_entries, RngKey key, int n_samples, float* arena, hipStream_t st);
-struct BnGradEntry { long long bsums_off; long long bn_off; int C; int hw; };      // hw = H * W of the normalised tensor
 // nn.BatchNorm2d's running statistics after n_samples training forwards (batch sums in fstats), and their use in eval mode
 int launch_bn_update_running(const BnGradEntry* table_dev, int n_entries, int max_c, const double* fstats_base, int n_samples, float momentum,
                              float* running, hipStream_t st);

@@ -646,16 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 __global__ void bn_param_grads_kernel(const BnGradEntry* __restrict__ table, const double* __restrict__ bsums_base,
                                       int n_samples, float* __restrict__ dbn)
 {
-    const BnGradEntry e = table[blockIdx.x];
-    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
-        double sb = 0, sg = 0;
-        for (int k = 0; k < n_samples; ++k) {
-            const double* s = bsums_base + e.bsums_off + ((long long)k * e.C + c) * 2;
-            sb += s[0]; sg += s[1];
-        }
-        dbn[e.bn_off + c] += (float)sg;            // d gamma = sum ga * xhat
-        dbn[e.bn_off + e.C + c] += (float)sb;      // d beta  = sum ga
-    }
+    bn_param_grads_entry(table[blockIdx.x], bsums_base, n_samples, dbn);
 }
 
 // nn.BatchNorm2d(momentum = 0.1) in training mode (models/common.py:96-97) after each of the n_samples batch-1 forwards, in order:

@@ -258,12 +258,36 @@ __global__ void step_advance_kernel(int* __restrict__ t_applied, StepGuard guard
 // one-block kernel adds up in block order right behind: deterministic, and no same-address atomic chain (a ticket / atomicAdd
 // per block serialises at ~70 ns each: 2048 blocks cost 150 us on MI355X).
 constexpr int ELBO_UPDATE_MAX_BLOCKS = 2048;
-struct ElboUpdateScratch { double partial[ELBO_UPDATE_MAX_BLOCKS]; };
+struct ElboUpdateScratch { double partial[ELBO_UPDATE_MAX_BLOCKS]; unsigned done; unsigned pad; };      // done: blocks of the running launch that have published their partial (zero between launches)
+
+// The KL total by the launch's LAST block (round 4: the separate one-block finish launch cost a dependent launch at the tail of every
+// iteration): every block publishes its partial, then counts itself; the block that counts last reads all partials in the fixed order the
+// finish kernel used (thread-strided, then the block reduction: bit-identical sum), writes kl_out, advances the guarded step counter and
+// puts the counter back to zero.  The scratch must be zero when the first launch sees it (header).
+__device__ __forceinline__ void elbo_finish_by_last_block(ElboUpdateScratch* __restrict__ sc, double tot, double* __restrict__ kl_out, int* __restrict__ t_applied, bool skip,
+                                                          double* s_red)
+{
+    __shared__ bool s_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sc->partial[blockIdx.x]), (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = __hip_atomic_fetch_add(&sc->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double t = 0;
+    // device-scope atomic loads: the partials were written by blocks on other XCDs (their own L2)
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
+        t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&sc->partial[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    t = block_sum_d(t, s_red);
+    if (threadIdx.x == 0) { *kl_out = t; if (t_applied && !skip) *t_applied += 1; sc->done = 0u; }
+}
 
 __global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                           long long n_vi, long long n_bn, float m0, float s0, float temp, float b1, float b2,
                                                           float eps, float step_size, float inv_sqrt_bc2, ElboUpdateScratch* __restrict__ sc, float lr,
-                                                          StepGuard guard)
+                                                          StepGuard guard, double* __restrict__ kl_out, int* __restrict__ t_applied)
 {
     __shared__ double s_red[8];
     __shared__ float s_bc[2];
@@ -290,18 +314,8 @@ __global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p,
     if (!skip)
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) adam(2 * n_vi + i, g[2 * n_vi + i]);
     const double tot = block_sum_d(acc, s_red);
-    if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
+    elbo_finish_by_last_block(sc, tot, kl_out, t_applied, skip, s_red);
 }
-__global__ __launch_bounds__(256) void elbo_update_finish_kernel(const ElboUpdateScratch* __restrict__ sc, int n_blocks, double* __restrict__ kl_out,
-                                                                 int* __restrict__ t_applied, StepGuard guard)
-{
-    __shared__ double s_red[8];
-    double t = 0;
-    for (int b = threadIdx.x; b < n_blocks; b += 256) t += sc->partial[b];
-    t = block_sum_d(t, s_red);
-    if (threadIdx.x == 0) { *kl_out = t; if (t_applied && !guard_skip(guard)) *t_applied += 1; }
-}
-
 // nearest /f projection x[..., ::f, ::f] (the SR runner's downsampler: bayesian_optimization.py:2095-2099)
 __global__ __launch_bounds__(256) void decimate_kernel(const float* __restrict__ src, int W, int f, int h, int w, float* __restrict__ dst)
 {
@@ -498,8 +512,13 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
                                                             const float* __restrict__ part_base, const void* __restrict__ rho_v,
                                                             RngKey key, int sample_weights, int n_samples,
                                                             float* __restrict__ dmu, float* __restrict__ drho,
-                                                            const float* __restrict__ wsamp, long long wstride, const void* __restrict__ mu_v)
+                                                            const float* __restrict__ wsamp, long long wstride, const void* __restrict__ mu_v,
+                                                            int n_main_blocks, const BnGradEntry* __restrict__ bn_table, const double* __restrict__ bsums_base,
+                                                            float* __restrict__ dbn)
 {
+    // blocks behind the weight-gradient blocks: the BatchNorm parameter gradients, one table entry each (round 4: bn_param_grads_kernel was a
+    // dependent launch of its own at the tail of every iteration)
+    if ((int)blockIdx.x >= n_main_blocks) { bn_param_grads_entry(bn_table[(int)blockIdx.x - n_main_blocks], bsums_base, n_samples, dbn); return; }
     key = key_now(key);
     typedef typename std::conditional<BF16, bf16_t, float>::type PT;
     const PT* __restrict__ rho = static_cast<const PT*>(rho_v); const PT* __restrict__ mu = static_cast<const PT*>(mu_v);
@@ -599,9 +618,12 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
 template <bool BF16>
 __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* __restrict__ table, int n_entries,
                                                              const void* __restrict__ mu_v, const void* __restrict__ rho_v,
-                                                             RngKey key, float* __restrict__ wsamp, long long wstride, int sample)
+                                                             RngKey key, float* __restrict__ wsamp, long long wstride, int sample,
+                                                             double* __restrict__ zero, long long n_zero)
 {
     key = key_now(key);
+    // the pass's statistics buffers, cleared by the draw's own threads (plan.hip, mfvi_forward)
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n_zero; i += (long long)gridDim.x * gridDim.y * 256) zero[i] = 0.0;
     typedef typename std::conditional<BF16, bf16_t, float>::type PT;
     const PT* __restrict__ mu = static_cast<const PT*>(mu_v); const PT* __restrict__ rho = static_cast<const PT*>(rho_v);
     __shared__ int s_first[TABLE_LDS];
@@ -656,7 +678,7 @@ __global__ __launch_bounds__(256) void round_bf16_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void elbo_update_bf16_kernel(bf16_t* __restrict__ pm, bf16_t* __restrict__ pr, float* __restrict__ bn, float* __restrict__ g, float* __restrict__ m,
                                                                float* __restrict__ v, long long n_vi, long long n_bn, float m0, float s0, float temp,
                                                                float b1, float b2, float eps, float step_size, float inv_sqrt_bc2, RngKey key,
-                                                               ElboUpdateScratch* __restrict__ sc)
+                                                               ElboUpdateScratch* __restrict__ sc, double* __restrict__ kl_out)
 {
     key = key_now(key);
     __shared__ double s_red[8];
@@ -690,7 +712,7 @@ __global__ __launch_bounds__(256) void elbo_update_bf16_kernel(bf16_t* __restric
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) bn[i] = adam(2 * n_vi + i, g[2 * n_vi + i], bn[i]);
     const double tot = block_sum_d(acc, s_red);
-    if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
+    elbo_finish_by_last_block(sc, tot, kl_out, nullptr, false, s_red);
 }
 
 }  // namespace
@@ -703,11 +725,11 @@ int launch_dropout_masks(const DropEntry* table_dev, int n_entries, RngKey key, 
 }
 
 int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blocks, const void* mu, const void* rho, RngKey key,
-                          int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16, int sample)
+                          int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16, int sample, double* zero, long long n_zero)
 {
-    if (n_entries < 1 || n_blocks < 1) return 0;
-    if (bf16) hipLaunchKernelGGL(sample_weights_kernel<true>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample);
-    else hipLaunchKernelGGL(sample_weights_kernel<false>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample);
+    if (n_entries < 1 || n_blocks < 1) { if (n_zero > 0) return (int)hipMemsetAsync(zero, 0, sizeof(double) * n_zero, st); return 0; }
+    if (bf16) hipLaunchKernelGGL(sample_weights_kernel<true>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample, zero, n_zero);
+    else hipLaunchKernelGGL(sample_weights_kernel<false>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample, zero, n_zero);
     return (int)hipGetLastError();
 }
 
@@ -720,13 +742,14 @@ int launch_expand_bf16(const void* src, long long n, float* dst, hipStream_t st)
 
 int launch_grad_finalize(const GradFinEntry* table_dev, int n_entries, int n_blocks, const float* part_base, const void* rho, RngKey key,
                          int sample_weights, int n_samples, float* dmu, float* drho, const float* wsamp, long long wstride, const void* mu,
-                         hipStream_t st, int bf16)
+                         hipStream_t st, int bf16, const BnGradEntry* bn_table, int n_bn, const double* bsums_base, float* dbn)
 {
-    if (n_entries < 1 || n_blocks < 1) return 0;
-    if (bf16) hipLaunchKernelGGL(grad_finalize_kernel<true>, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
-                                 n_samples, dmu, drho, wsamp, wstride, mu);
-    else hipLaunchKernelGGL(grad_finalize_kernel<false>, dim3(n_blocks), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
-                            n_samples, dmu, drho, wsamp, wstride, mu);
+    if (n_entries < 1 || n_blocks < 1) return 0;      // (the caller launches bn_param_grads itself when there is nothing to reduce)
+    if (!bn_table || !dbn) n_bn = 0;
+    if (bf16) hipLaunchKernelGGL(grad_finalize_kernel<true>, dim3(n_blocks + n_bn), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
+                                 n_samples, dmu, drho, wsamp, wstride, mu, n_blocks, bn_table, bsums_base, dbn);
+    else hipLaunchKernelGGL(grad_finalize_kernel<false>, dim3(n_blocks + n_bn), dim3(256), 0, st, table_dev, n_entries, part_base, rho, key, sample_weights,
+                            n_samples, dmu, drho, wsamp, wstride, mu, n_blocks, bn_table, bsums_base, dbn);
     return (int)hipGetLastError();
 }
 
@@ -820,9 +843,7 @@ int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
                        prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (ElboUpdateScratch*)scratch, lr,
-                       StepGuard{nullptr, nullptr, nullptr});
-    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, (int*)nullptr,
-                       StepGuard{nullptr, nullptr, nullptr});
+                       StepGuard{nullptr, nullptr, nullptr}, kl_out, (int*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -836,8 +857,7 @@ int mfvi_elbo_update_guarded(float* params, float* grads, float* m, float* v, in
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     const StepGuard guard{t_applied, loss_d, loss_f};
     hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
-                       prior_mu, prior_sigma, temp, beta1, beta2, eps, 0.f, 0.f, (ElboUpdateScratch*)scratch, lr, guard);
-    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, t_applied, guard);
+                       prior_mu, prior_sigma, temp, beta1, beta2, eps, 0.f, 0.f, (ElboUpdateScratch*)scratch, lr, guard, kl_out, (int*)t_applied);
     return (int)hipGetLastError();
 }
 
@@ -877,9 +897,7 @@ int mfvi_elbo_update_bf16(void* mu_bf16, void* rho_bf16, float* bn, float* grads
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     hipLaunchKernelGGL(elbo_update_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (bf16_t*)mu_bf16, (bf16_t*)rho_bf16, bn, grads, m, v, (long long)n_vi,
                        (long long)n_bn, prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)),
-                       make_key(seed, DOMAIN_ROUND, 0, 0, (uint32_t)t), (ElboUpdateScratch*)scratch);
-    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, (int*)nullptr,
-                       StepGuard{nullptr, nullptr, nullptr});
+                       make_key(seed, DOMAIN_ROUND, 0, 0, (uint32_t)t), (ElboUpdateScratch*)scratch, kl_out);
     return (int)hipGetLastError();
 }
 

@@ -565,9 +565,18 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
     if (bf16 && (((uintptr_t)mu_v | (uintptr_t)rho_v) & 7)) { set_error("forward: bf16 mu / rho must be 8-byte aligned"); return -1; }
     const float* mu = nullptr; const float* rho = nullptr;
     { const int rc = generic_params(plan, c, mu_v, rho_v, &mu, &rho, st); if (rc) { set_error("forward: bf16 expansion failed: %s", hipGetErrorString((hipError_t)rc)); return rc; } }
-    if (plan->stats_doubles) {      // forward statistics and (adjacent) the BN-backward sums of the backward pass that follows: one launch
-        hipError_t e = hipMemsetAsync(c.fstats(), 0, sizeof(double) * 2 * plan->stats_doubles, st);
-        if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    // MFMA-served layers: draw every weight once per (layer, sample); without sampling the kernels read mu (stride 0)
+    // (bf16 parameters: the slab also serves w = mu, as one float32 copy shared by all samples)
+    const bool presample = use_mfma() && (sample_weights || bf16) && plan->n_samp > 0;
+    // The forward statistics and (adjacent) the BN-backward sums of the backward pass that follows start every pass from zero.  With a weight
+    // draw in front of the pass the draw's kernel clears them with its own threads (round 4: the memset was a dependent 6 us launch at the
+    // head of every iteration); eval-mode BatchNorm fills the statistics in front of the draw and keeps the memset.
+    const bool zero_in_draw = plan->stats_doubles && presample && !(plan->bn_eval && plan->n_entries);
+    if (plan->stats_doubles) {
+        if (!zero_in_draw) {
+            hipError_t e = hipMemsetAsync(c.fstats(), 0, sizeof(double) * 2 * plan->stats_doubles, st);
+            if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
         plan->bsums_clean_ws = workspace;
     }
     const RngKey key = base_key(seed, step, k0, plan->step_dev);
@@ -580,13 +589,10 @@ int mfvi_forward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const flo
         const int rc = launch_lrt_sigma2(rho, plan->n_vi, c.farena() + plan->sig2_off, st);
         if (rc) { set_error("forward: sigma^2 launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
-    // MFMA-served layers: draw every weight once per (layer, sample); without sampling the kernels read mu (stride 0)
-    // (bf16 parameters: the slab also serves w = mu, as one float32 copy shared by all samples)
-    const bool presample = use_mfma() && (sample_weights || bf16) && plan->n_samp > 0;
     if (presample) {
         ProfScope ps(plan, -1, PASS_SAMPLE, st);
         const int rc = launch_sample_weights(plan->samp_dev, plan->n_samp, plan->samp_blocks, mu_v, rho_v, key, sample_weights ? n_samples : 1, c.wsamp(),
-                                             plan->n_vi, st, bf16, sample_weights);
+                                             plan->n_vi, st, bf16, sample_weights, zero_in_draw ? c.fstats() : nullptr, zero_in_draw ? 2 * plan->stats_doubles : 0);
         if (rc) { set_error("forward: sample_weights launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
         plan->samp_mu = mu_v; plan->samp_rho = rho_v; plan->samp_ws = workspace; plan->samp_seed = seed; plan->samp_step = step; plan->samp_k0 = k0;
         plan->samp_n = sample_weights ? n_samples : -n_samples;
@@ -828,7 +834,8 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         if (mfvi_tl_stop_event) { mfvi_tl_stop_event = nullptr; armed_idx = -1; }
     };
     // reduction of the partial dW slabs of the layers collected in `fin` into dmu / drho, on stream fs from the device table tab
-    auto finalize = [&](hipStream_t fs, GradFinEntry* tab, std::vector<GradFinEntry>& uploaded) -> int {
+    bool bn_done = false;      // the BatchNorm parameter gradients went out with the last grad_finalize launch
+    auto finalize = [&](hipStream_t fs, GradFinEntry* tab, std::vector<GradFinEntry>& uploaded, bool with_bn = false) -> int {
         if (fin.empty()) return 0;
         // longest blocks first: a block's work grows with the number of pixel strips of its layer
         std::stable_sort(fin.begin(), fin.end(), [](const GradFinEntry& a, const GradFinEntry& b) { return a.strips > b.strips; });
@@ -846,8 +853,10 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
         }
         // every layer of `fin` (MFMA backward-weight) is also in the sampling table (same shape conditions), so its W_k sit in the slab
         const int rc = launch_grad_finalize(tab, (int)fin.size(), fin_blocks, c.farena(), rho_v, key, sample_weights, n_samples, dmu, drho,
-                                            presample && sample_weights && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu_v, fs, bf16);
+                                            presample && sample_weights && grad_from_slab() ? c.wsamp() : nullptr, plan->n_vi, mu_v, fs, bf16,
+                                            with_bn ? plan->table_dev : nullptr, with_bn ? plan->n_entries : 0, c.bsums(), dbn);
         if (rc) { set_error("backward: grad_finalize launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+        if (with_bn && plan->n_entries) bn_done = true;
         fin.clear(); fin_blocks = 0;
         return 0;
     };
@@ -1017,13 +1026,16 @@ int mfvi_backward(mfvi_plan* plan, const void* mu_v, const void* rho_v, const fl
     }
     {   // the rest (or all) of the layers: the late group of a split pass has its own table slot
         const bool was_split = plan->split_op >= 0 && plan->split_stream && plan->split_stream != st;
-        const int rc = was_split ? finalize(st, plan->fin_dev + 2 * plan->n_conv, plan->fin_uploaded_late) : finalize(st, plan->fin_dev, plan->fin_uploaded);
+        // (the BatchNorm parameter gradients ride on this launch: every fold that feeds the BN-backward sums ran on `st` in front of it.
+        //  Not with local-reparameterisation layers: their d rho kernel in between touches neither, but keeps the old order for its tests)
+        const bool with_bn = plan->n_entries > 0 && plan->n_lrt == 0;
+        const int rc = was_split ? finalize(st, plan->fin_dev + 2 * plan->n_conv, plan->fin_uploaded_late, with_bn) : finalize(st, plan->fin_dev, plan->fin_uploaded, with_bn);
         if (rc) return rc; }
     if (plan->n_lrt && sample_weights) {      // d rho += d sigma^2 * 2 softplus(rho) sigmoid(rho)
         const int rc = launch_lrt_drho(c.farena() + plan->dsig2_off, rho, plan->n_vi, drho, st);
         if (rc) { set_error("backward: lrt_drho launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
-    if (plan->n_entries) {
+    if (plan->n_entries && !bn_done) {
         const int rc = launch_bn_param_grads(plan->table_dev, plan->n_entries, plan->max_c, c.bsums(), n_samples, dbn, st);
         if (rc) { set_error("backward: bn_param_grads launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     }
