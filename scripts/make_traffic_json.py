@@ -20,7 +20,7 @@ def csrc_sha256():
 def kernel_pass(name, ks):
     """which pass of the kxk layer under test a kernel name of the table belongs to (None: one of the 1x1 helper layers)"""
     if name.startswith("conv_fwd_x6_kernel"): return "fwd"
-    if name.startswith("conv_bwd_x6_kernel"): return "bwd_data"
+    if name.startswith("conv_bwd_x6_kernel") or name.startswith("conv_bwd_x6s_kernel"): return "bwd_data"
     if name.startswith("conv_bww_x6_kernel") or name.startswith("conv_bww_split_kernel"): return "bwd_weight"
     m = re.match(r"conv_rp_kernel<(\d)", name)
     if m: return "fwd" if m.group(1) == "0" else "bwd_data"
