@@ -269,15 +269,18 @@ __device__ __forceinline__ void elbo_finish_by_last_block(ElboUpdateScratch* __r
 {
     __shared__ bool s_last;
     if (threadIdx.x == 0) {
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&sc->partial[blockIdx.x]), (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        s_last = __hip_atomic_fetch_add(&sc->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        // No fence: a device-scope release on this machine writes the XCD's whole L2 back (buffer_wbl2) — 2048 of them made this 15 us kernel
+        // take 150.  Both steps are device-scope read-modify-write atomics, performed at the coherence point; the exchange RETURNS a value, so
+        // waiting for it (vmcnt) means it has been performed before the counter's increment is issued.
+        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(&sc->partial[blockIdx.x]), (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&sc->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     double t = 0;
-    // device-scope atomic loads: the partials were written by blocks on other XCDs (their own L2)
+    // device-scope atomic loads (they bypass this XCD's L2): the partials were published by blocks on other XCDs
     for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
         t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&sc->partial[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     t = block_sum_d(t, s_red);

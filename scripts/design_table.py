@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Markdown rows of DESIGN.md's results table from profiles/r03_bench_*.json (one bench line each)."""
+"""Markdown rows of DESIGN.md's results table from profiles/r04_bench_*.json (one bench line each)."""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = [("cfg1", "den 128², K=4"), ("cfg2", "den 256², K=16"), ("cfg3", "SR ×4 512², depth 32, K=8"), ("cfg4", "CT 256², 45 angles, K=16"),
@@ -7,7 +7,7 @@ rows = [("cfg1", "den 128², K=4"), ("cfg2", "den 256², K=16"), ("cfg3", "SR ×
         ("cfg2_k1", "cfg2 `--k 1`: the reference's own loop shape"), ("dropin", "`--mode dropin --k 1`: INTEGRATION.md loop, `torch.optim.AdamW` over 254 Parameters"),
         ("dropin_flat", "`--mode dropin --k 1 --flat-parameters`: `MeanFieldVI(flat_parameters=True)`")]
 for key, what in rows:
-    f = os.path.join(ROOT, "profiles", "r03_bench_%s.json" % key)
+    f = os.path.join(ROOT, "profiles", "r04_bench_%s.json" % key)
     if not os.path.exists(f):
         continue
     d = json.loads(open(f).read().strip().split("\n")[-1])

@@ -16,6 +16,7 @@ export MFVI_TUNE_CACHE=$R/$OUT/tunes_cfg2.json      # absolute: the profiled com
 python3 bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 python3 bench.py --profile-all --no-cpu-baseline --no-gpu-baseline --steps 20 2> $OUT/kernel_table_cfg2.txt > /dev/null
 cd /tmp
+rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write /tmp/p_trace      # (a reused box keeps /tmp: the copies below take the first match)
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gpu-baseline > /dev/null 2>&1
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $R/$OUT/kernel_stats_cfg2.csv
 python3 $R/scripts/timeline.py $(find /tmp/p_stats -name "*kernel_trace.csv" | head -1) > $R/$OUT/timeline.txt
