@@ -17,6 +17,6 @@ for key, what in rows:
         extra += "; %d with bookkeeping" % round(d["elbo_iters_per_sec_with_bookkeeping"])
     if d.get("fwd_only_mc_passes_per_sec") and key.startswith("cfg") and "k1" not in key:
         extra += "; forward-only %d" % round(d["fwd_only_mc_passes_per_sec"])
-    dom = "latency-bound" if r.get("alone", {}).get("frac", 0) < 0.2 else "%s: %.2f / %.2f" % (r["kernel"].split(":")[1].split(",")[0].strip().replace("3x3 conv ", "bwd-data "), r["alone"]["frac"], r["frac"])
+    dom = "latency-bound" if r.get("alone", {}).get("frac", 0) < 0.2 else "%s: %.2f / %.2f" % ((r["kernel"].split(" of ")[0].replace("bwd_data", "bwd-data").replace("bwd_weight", "bwd-weight") + " " + r["kernel"].split(":")[1].split(",")[0].strip().replace("3x3 conv ", "")), r["alone"]["frac"], r["frac"])
     x6 = d.get("bf16x6_kernels")
     print("| %s | %s | **%.2f** | %d (%s) | %s | %s |" % (key, what, d["ms_per_step"], round(d["value"]), extra, dom, len(x6) if x6 is not None else "—"))
