@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define MFVI_ABI_VERSION 7
+#define MFVI_ABI_VERSION 6
 
 typedef struct mfvi_plan mfvi_plan;
 
@@ -243,10 +243,8 @@ int mfvi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 /* The deterministic tail of one ELBO iteration in one pass over the parameters (bayesian_optimization.py:1368-1372): kl_out = KL of all n_vi
  * (mu, rho) pairs, grads += temp * dKL (written back), then AdamW(weight_decay = 0) on the flat blocks [MU | RHO | BN] of
  * params / grads / m / v (2*n_vi + n_bn floats each).  Same per-element arithmetic as mfvi_kl + mfvi_kl_backward +
- * mfvi_adam_step; the KL sum is reduced in a fixed order (bit-reproducible) by the launch's last block (no second launch).  scratch:
- * mfvi_elbo_update_scratch_bytes() bytes of device memory, ZEROED ONCE by the caller before the first call and left alone afterwards
- * (per-block partial sums + the count of blocks that have published theirs, which every call puts back to zero; ABI v7 — up to v6 the
- * contents were free).  One scratch buffer serves one stream at a time. */
+ * mfvi_adam_step; the KL sum is reduced in a fixed order (bit-reproducible).  scratch: mfvi_elbo_update_scratch_bytes()
+ * bytes of device memory (per-block partial sums; contents need not be preserved between calls). */
 int64_t mfvi_elbo_update_scratch_bytes(void);
 int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_vi, int64_t n_bn, float prior_mu, float prior_sigma,
                      float temp, float lr, float beta1, float beta2, float eps, int t, double* kl_out, void* scratch, void* stream);

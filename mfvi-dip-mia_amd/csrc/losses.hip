@@ -258,39 +258,12 @@ __global__ void step_advance_kernel(int* __restrict__ t_applied, StepGuard guard
 // one-block kernel adds up in block order right behind: deterministic, and no same-address atomic chain (a ticket / atomicAdd
 // per block serialises at ~70 ns each: 2048 blocks cost 150 us on MI355X).
 constexpr int ELBO_UPDATE_MAX_BLOCKS = 2048;
-struct ElboUpdateScratch { double partial[ELBO_UPDATE_MAX_BLOCKS]; unsigned done; unsigned pad; };      // done: blocks of the running launch that have published their partial (zero between launches)
-
-// The KL total by the launch's LAST block (round 4: the separate one-block finish launch cost a dependent launch at the tail of every
-// iteration): every block publishes its partial, then counts itself; the block that counts last reads all partials in the fixed order the
-// finish kernel used (thread-strided, then the block reduction: bit-identical sum), writes kl_out, advances the guarded step counter and
-// puts the counter back to zero.  The scratch must be zero when the first launch sees it (header).
-__device__ __forceinline__ void elbo_finish_by_last_block(ElboUpdateScratch* __restrict__ sc, double tot, double* __restrict__ kl_out, int* __restrict__ t_applied, bool skip,
-                                                          double* s_red)
-{
-    __shared__ bool s_last;
-    if (threadIdx.x == 0) {
-        // No fence: a device-scope release on this machine writes the XCD's whole L2 back (buffer_wbl2) — 2048 of them made this 15 us kernel
-        // take 150.  Both steps are device-scope read-modify-write atomics, performed at the coherence point; the exchange RETURNS a value, so
-        // waiting for it (vmcnt) means it has been performed before the counter's increment is issued.
-        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(&sc->partial[blockIdx.x]), (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(&sc->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    double t = 0;
-    // device-scope atomic loads (they bypass this XCD's L2): the partials were published by blocks on other XCDs
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
-        t += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&sc->partial[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    t = block_sum_d(t, s_red);
-    if (threadIdx.x == 0) { *kl_out = t; if (t_applied && !skip) *t_applied += 1; sc->done = 0u; }
-}
+struct ElboUpdateScratch { double partial[ELBO_UPDATE_MAX_BLOCKS]; };
 
 __global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                           long long n_vi, long long n_bn, float m0, float s0, float temp, float b1, float b2,
                                                           float eps, float step_size, float inv_sqrt_bc2, ElboUpdateScratch* __restrict__ sc, float lr,
-                                                          StepGuard guard, double* __restrict__ kl_out, int* __restrict__ t_applied)
+                                                          StepGuard guard)
 {
     __shared__ double s_red[8];
     __shared__ float s_bc[2];
@@ -317,8 +290,18 @@ __global__ __launch_bounds__(256) void elbo_update_kernel(float* __restrict__ p,
     if (!skip)
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) adam(2 * n_vi + i, g[2 * n_vi + i]);
     const double tot = block_sum_d(acc, s_red);
-    elbo_finish_by_last_block(sc, tot, kl_out, t_applied, skip, s_red);
+    if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
 }
+__global__ __launch_bounds__(256) void elbo_update_finish_kernel(const ElboUpdateScratch* __restrict__ sc, int n_blocks, double* __restrict__ kl_out,
+                                                                 int* __restrict__ t_applied, StepGuard guard)
+{
+    __shared__ double s_red[8];
+    double t = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) t += sc->partial[b];
+    t = block_sum_d(t, s_red);
+    if (threadIdx.x == 0) { *kl_out = t; if (t_applied && !guard_skip(guard)) *t_applied += 1; }
+}
+
 // nearest /f projection x[..., ::f, ::f] (the SR runner's downsampler: bayesian_optimization.py:2095-2099)
 __global__ __launch_bounds__(256) void decimate_kernel(const float* __restrict__ src, int W, int f, int h, int w, float* __restrict__ dst)
 {
@@ -681,7 +664,7 @@ __global__ __launch_bounds__(256) void round_bf16_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void elbo_update_bf16_kernel(bf16_t* __restrict__ pm, bf16_t* __restrict__ pr, float* __restrict__ bn, float* __restrict__ g, float* __restrict__ m,
                                                                float* __restrict__ v, long long n_vi, long long n_bn, float m0, float s0, float temp,
                                                                float b1, float b2, float eps, float step_size, float inv_sqrt_bc2, RngKey key,
-                                                               ElboUpdateScratch* __restrict__ sc, double* __restrict__ kl_out)
+                                                               ElboUpdateScratch* __restrict__ sc)
 {
     key = key_now(key);
     __shared__ double s_red[8];
@@ -715,7 +698,7 @@ __global__ __launch_bounds__(256) void elbo_update_bf16_kernel(bf16_t* __restric
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_bn; i += (long long)gridDim.x * 256) bn[i] = adam(2 * n_vi + i, g[2 * n_vi + i], bn[i]);
     const double tot = block_sum_d(acc, s_red);
-    elbo_finish_by_last_block(sc, tot, kl_out, nullptr, false, s_red);
+    if (threadIdx.x == 0) sc->partial[blockIdx.x] = tot;
 }
 
 }  // namespace
@@ -846,7 +829,9 @@ int mfvi_elbo_update(float* params, float* grads, float* m, float* v, int64_t n_
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
                        prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (ElboUpdateScratch*)scratch, lr,
-                       StepGuard{nullptr, nullptr, nullptr}, kl_out, (int*)nullptr);
+                       StepGuard{nullptr, nullptr, nullptr});
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, (int*)nullptr,
+                       StepGuard{nullptr, nullptr, nullptr});
     return (int)hipGetLastError();
 }
 
@@ -860,7 +845,8 @@ int mfvi_elbo_update_guarded(float* params, float* grads, float* m, float* v, in
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     const StepGuard guard{t_applied, loss_d, loss_f};
     hipLaunchKernelGGL(elbo_update_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long long)n_vi, (long long)n_bn,
-                       prior_mu, prior_sigma, temp, beta1, beta2, eps, 0.f, 0.f, (ElboUpdateScratch*)scratch, lr, guard, kl_out, (int*)t_applied);
+                       prior_mu, prior_sigma, temp, beta1, beta2, eps, 0.f, 0.f, (ElboUpdateScratch*)scratch, lr, guard);
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, t_applied, guard);
     return (int)hipGetLastError();
 }
 
@@ -900,7 +886,9 @@ int mfvi_elbo_update_bf16(void* mu_bf16, void* rho_bf16, float* bn, float* grads
     const int nb = nblocks(work, ELBO_UPDATE_MAX_BLOCKS);
     hipLaunchKernelGGL(elbo_update_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (bf16_t*)mu_bf16, (bf16_t*)rho_bf16, bn, grads, m, v, (long long)n_vi,
                        (long long)n_bn, prior_mu, prior_sigma, temp, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)),
-                       make_key(seed, DOMAIN_ROUND, 0, 0, (uint32_t)t), (ElboUpdateScratch*)scratch, kl_out);
+                       make_key(seed, DOMAIN_ROUND, 0, 0, (uint32_t)t), (ElboUpdateScratch*)scratch);
+    hipLaunchKernelGGL(elbo_update_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const ElboUpdateScratch*)scratch, nb, kl_out, (int*)nullptr,
+                       StepGuard{nullptr, nullptr, nullptr});
     return (int)hipGetLastError();
 }
 

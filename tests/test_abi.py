@@ -32,7 +32,7 @@ def test_ctypes_table_matches_header():
     import mfvi_dip_mia_amd as M
     assert sorted(M._lib.SIGNATURES) == declared_symbols()
     L = M._lib.lib()
-    assert L.mfvi_abi_version() == 7
+    assert L.mfvi_abi_version() == 6
     assert isinstance(L.mfvi_last_error(), bytes)
 
 
