@@ -114,7 +114,11 @@ struct X6FArgs {
     int COp, ncg, rem, bands, strips, tpb, nx, ny, nz;    // tpb: consecutive strips of a band per block
 };
 
-template <int MF, int SR>
+// MRG (round 4, one output fragment per wave only): the remainder plane rides on the LAST group's pass — its three tap-row operands stay in
+// registers beside the group's 27 (36 more), the staging waves write the plane in the same stages, a window row's matrix work is its
+// 3 x 18 + 18 instructions in one sweep.  The 36 -> 16 layer is then ONE pass of five stages per strip instead of two (the second one
+// re-ran the whole row pipeline, barriers and window staging included, for a quarter of the matrix work).
+template <int MF, int SR, bool MRG>
 __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
 {
     using C = X6FCfg;
@@ -140,7 +144,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
     const int c0 = band * 64, co0 = by * COB;
     const int Cin = g.Cin, Cout = g.Cout, H = g.H, W = g.W, HW = H * W;
     const int ncg = A.ncg, rem = A.rem;
-    const int n_stage1 = (ncg + rem) * ((SR + 2) / 2);     // stages per strip: two input rows per stage; the remainder plane is a pass of its own (its weights take the place of a group's in the registers)
+    static_assert(!MRG || MF == 1, "merged remainder: 144 weight registers, one output fragment per wave");
+    const int n_stage1 = (ncg + (MRG ? 0 : rem)) * ((SR + 2) / 2);     // stages per strip: two input rows per stage; the remainder plane is a pass of its own (its weights take the place of a group's in the registers)
     const int n_stage = n_strip * n_stage1;
     const float* __restrict__ xin = A.in.data + (long long)k * A.in.sstride;
 
@@ -223,27 +228,29 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
                 put(va[set], kas, kah, base + sa * SLOT);
                 put(vb[set], kas, kah, base + sb * SLOT);
             }
-            if (cg < ncg ? c_halo : c_rem) put(vc[set], kcs, kch, lds + (c_row ? sb : sa) * SLOT + c_oct * PLANE + c_col * 16);
+            if (MRG ? (c_halo || (c_rem && cg == ncg - 1)) : (cg < ncg ? c_halo : c_rem)) put(vc[set], kcs, kch, lds + (c_row ? sb : sa) * SLOT + c_oct * PLANE + c_col * 16);
         };
         (void)c_on;
         // weight pieces of pass pp (strip pp / passes, group pp % passes): 27 (remainder: 9) chunks of COB x 64 bytes -> s_w, requested in
         // stage 1 of the pass before and stored in its stage 2 (the matrix waves took their copy at the head of stage 0)
-        constexpr int NWU = (27 * COB * 4 + 255) / 256;
-        const int passes = ncg + rem, n_pass = n_strip * passes;
+        constexpr int NWC = MRG ? 36 : 27;                  // 16-byte-unit chunks of a pass's weight pieces (merged: the group's 27 + the remainder's 9)
+        constexpr int NWU = (NWC * COB * 4 + 255) / 256;
+        const int passes = ncg + (MRG ? 0 : rem), n_pass = n_strip * passes;
         const unsigned* __restrict__ wsp = A.wsp + (long long)k * A.wsp_stride_u4 * 4;
         u32x4 wq[NWU];
         auto wfetch = [&](int pp) {
             const int cg = pp % passes;
-            const int nu = (cg == ncg ? 9 : 27) * COB * 4;
+            const int nu = (MRG ? ((rem && cg == ncg - 1) ? 36 : 27) : (cg == ncg ? 9 : 27)) * COB * 4;
 #pragma unroll
             for (int j = 0; j < NWU; ++j) {
                 const int u = min(t + 256 * j, nu - 1), c = u / (COB * 4), within = u - c * (COB * 4);
-                wq[j] = *reinterpret_cast<const u32x4*>(wsp + ((long long)(cg * 27 + c) * A.COp * 4 + co0 * 4 + within) * 4);
+                const int src = (MRG && c >= 27) ? ncg * 27 + (c - 27) : cg * 27 + c;      // (merged: chunks 27 .. 35 = the remainder's three tap rows x three pieces)
+                wq[j] = *reinterpret_cast<const u32x4*>(wsp + ((long long)src * A.COp * 4 + co0 * 4 + within) * 4);
             }
         };
         auto wstore = [&]() {
 #pragma unroll
-            for (int j = 0; j < NWU; ++j) if (t + 256 * j < 27 * COB * 4) *reinterpret_cast<u32x4*>(s_w + (t + 256 * j) * 16) = wq[j];
+            for (int j = 0; j < NWU; ++j) if (t + 256 * j < NWC * COB * 4) *reinterpret_cast<u32x4*>(s_w + (t + 256 * j) * 16) = wq[j];
         };
         constexpr int SPP = (SR + 2) / 2;                   // stages per pass
         wfetch(0);
@@ -295,11 +302,18 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
         for (int o = 0; o < SR; ++o)
 #pragma unroll
             for (int f = 0; f < PF; ++f) acc[o][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int cg = 0; cg < ncg + rem; ++cg) {
-            const bool is_rem = cg == ncg;
+        for (int cg = 0; cg < ncg + (MRG ? 0 : rem); ++cg) {
+            const bool is_rem = !MRG && cg == ncg, with_rem = MRG && rem && cg == ncg - 1;
             u32x4 Wr[9][3];
-            auto rows = [&](auto rem_c) {
-                constexpr bool REM = decltype(rem_c)::value;
+            u32x4 Wm[MRG ? 3 : 1][3];                       // merged: the remainder's tap rows
+            auto rows = [&](auto rem_c, auto wr_c) {
+                constexpr bool REM = decltype(rem_c)::value, WR = decltype(wr_c)::value;
+                if constexpr (WR) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) Wm[ky][p] = *reinterpret_cast<const u32x4*>(swl + ((27 + ky * 3 + p)) * COB * 64);
+                }
 #pragma unroll
                 for (int tp = 0; tp < (REM ? 3 : 9); ++tp)
 #pragma unroll
@@ -307,11 +321,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
                 // groups of a row: (fragment f, kx) -> three pieces of the pixel operand, 18 matrix instructions against the three tap rows
                 // (remainder pass: one group per fragment).  The reads of group j + 1 are issued in front of group j's matrix instructions,
                 // those of the next row's first group in front of this row's last one when both rows belong to one stage.
-                constexpr int GF = REM ? 1 : 3, GR = PF * GF;
+                constexpr int GF = REM ? 1 : 3, GM = PF * GF, GR = GM + (WR ? PF : 0);      // groups of a row: the main ones, then (merged) the remainder's
                 u32x4 X[2][3];
                 auto issue = [&](int j, int slot, u32x4 (&x)[3]) {
-                    const int f = j / GF, kx = j - f * GF;
-                    const char* p = (REM ? xr : xl + kx * 16) + slot + f * 256;
+                    const bool rg = WR && j >= GM;
+                    const int f = rg ? j - GM : j / GF, kx = rg ? 0 : j - f * GF;
+                    const char* p = ((REM || rg) ? xr : xl + kx * 16) + slot + f * 256;
 #pragma unroll
                     for (int pc = 0; pc < 3; ++pc) x[pc] = *reinterpret_cast<const u32x4*>(p + pc * NOCT * PLANE);
                 };
@@ -324,7 +339,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
 #endif
 #pragma unroll
                     for (int j = 0; j < GR; ++j) {
-                        const int f = j / GF, kx = j - f * GF;
+                        const bool rg = WR && j >= GM;
+                        const int f = rg ? j - GM : j / GF, kx = rg ? 0 : j - f * GF;
 #ifdef X6F_DBG_NOMFMA
                         continue;
 #endif
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
                         for (int ky = 0; ky < 3; ++ky) {
                             const int o = ii - ky;
                             if (o < 0 || o >= SR) continue;
-                            const u32x4 (&Wk)[3] = Wr[REM ? ky : ky * 3 + kx];
+                            const u32x4 (&Wk)[3] = rg ? Wm[WR ? ky : 0] : Wr[REM ? ky : ky * 3 + kx];
                             const u32x4 (&Xo)[3] = X[(par + j) & 1];
                             f32x4 a = acc[o][f];
                             a = mfma_bf(Xo[2], Wk[0], a); a = mfma_bf(Xo[0], Wk[2], a); a = mfma_bf(Xo[1], Wk[1], a);
@@ -349,7 +365,9 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
                     if (ii & 1) { lds_barrier(); ++q; }
                 }
             };
-            if (is_rem) rows(std::true_type{}); else rows(std::false_type{});
+            if (is_rem) rows(std::true_type{}, std::false_type{});
+            else if (with_rem) { if constexpr (MRG) rows(std::false_type{}, std::true_type{}); }
+            else rows(std::false_type{}, std::false_type{});
         }
         // ---- epilogue: register r of (row o, fragment f) = pixel c0 + 16 (pf0 + f) + 4 l4 + r, channel co0 + 16 cf + l15 ----
         if (co < Cout) {
@@ -381,15 +399,15 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6_kernel(X6FArgs A)
     }
 }
 
-template <int MF, int SR>
+template <int MF, int SR, bool MRG = false>
 int launch_one(X6FArgs& A, hipStream_t st)
 {
     using C = X6FCfg;
-    constexpr size_t lds_bytes = (size_t)C::NSLOT * C::SLOT + (size_t)27 * 16 * MF * 64;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6_kernel<MF, SR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    constexpr size_t lds_bytes = (size_t)C::NSLOT * C::SLOT + (size_t)(MRG ? 36 : 27) * 16 * MF * 64;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6_kernel<MF, SR, MRG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return (int)attr;
     mfvi_tl_family = 3;
-    mfvi_launch((conv_fwd_x6_kernel<MF, SR>), dim3(A.nx * A.ny * A.nz), dim3(512), lds_bytes, st, A);
+    mfvi_launch((conv_fwd_x6_kernel<MF, SR, MRG>), dim3(A.nx * A.ny * A.nz), dim3(512), lds_bytes, st, A);
     return (int)hipGetLastError();
 }
 
@@ -430,8 +448,8 @@ int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long 
     if (in.act & MFVI_ACT_SQUARE) return -2;
     if ((out.sstride & 3) || ((uintptr_t)out.data & 15)) return -2;
     if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 31)) return -2;
-    const int mf = tune & 255, sr = (tune >> 8) & 255;
-    if ((mf != 1 && mf != 2) || sr != 8 || (g.H % sr)) return -3;
+    const int mf = tune & 255, sr = (tune >> 8) & 15, mrg = (tune >> 12) & 1;      // bit 12: the remainder plane rides on the last group's pass (mf = 1, Cin = 32 n + 4)
+    if ((mf != 1 && mf != 2) || sr != 8 || (g.H % sr) || (mrg && (mf != 1 || r32 == 0))) return -3;
     const int ncg = g.Cin / 32, rem = r32 ? 1 : 0, COp = (g.Cout + 31) / 32 * 32;
     const int n_k = wstride ? n_samples : 1;
     const long long units = (long long)(ncg * 9 + (rem ? 3 : 0)) * COp * 4;          // threads of the split kernel per sample
@@ -446,6 +464,7 @@ int launch_conv_fwd_x6(const TView& in, const ConvGeom& g, const float* w, long 
     const int T = max(1, (tune >> 16) & 255);
     A.strips = g.H / sr; A.tpb = T;
     A.nx = A.bands * ((A.strips + T - 1) / T); A.ny = (g.Cout + 16 * mf - 1) / (16 * mf); A.nz = n_samples;
+    if (mf == 1 && mrg) return launch_one<1, 8, true>(A, st);
     if (mf == 1) return launch_one<1, 8>(A, st);
     return launch_one<2, 8>(A, st);
 }

@@ -1204,6 +1204,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                     && (((long long)o.g.H * o.g.W) & 63) == 0) cands.push_back(1 | MFVI_TUNE_SM);
                 // bf16x6 forward (conv_x6.hip): output fragments per block, 8 output rows per block
                 if (which == 0 && o.x6w_off >= 0) for (int mf : {1, 2}) for (int T = 1; T <= 16; T *= 2) cands.push_back(mf | 8 << 8 | T << 16 | MFVI_TUNE_X6);
+                if (which == 0 && o.x6w_off >= 0 && (o.g.Cin & 31) == 4) for (int T = 1; T <= 16; T *= 2) cands.push_back(1 | 8 << 8 | 1 << 12 | T << 16 | MFVI_TUNE_X6);      // remainder plane on the last group's pass
                 // bf16x6 backward-data with the fold (conv_bwd_x6.hip): strips per block; rows per strip follow the output-channel count
                 if (which == 1 && o.x6bw_off >= 0) for (int T : {1, 2, 4, 8, 16, 32}) cands.push_back(T | (o.g.Cout == 16 ? 8 : o.g.Cout == 32 ? 4 : 2) << 8 | MFVI_TUNE_X6);
                 if (which == 1 && o.x6bw_off >= 0 && x6s_shape_ok(o.g)) for (int T : {2, 4, 8, 16, 32}) cands.push_back(T | 8 << 8 | 1 << 16 | MFVI_TUNE_X6);      // strip-resident form (conv_bwd_x6s.hip)

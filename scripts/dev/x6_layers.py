@@ -73,13 +73,13 @@ for cin, cout, hw in specs:
     basef = lib.mfvi_plan_get_tune(plan.handle, op, 0)
     us = measure(plan, op, bufs, 0)
     print("%d->%d @%d fwd        autotuned %#x: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak)" % (cin, cout, hw, basef, us, tf(us), tf(us) / 157.3), flush=True)
-    for mf, T in [(m_, t_) for m_ in (1, 2) for t_ in (1, 2, 4, 8)]:
-        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, mf | 8 << 8 | T << 16 | 1 << 25))
+    for mf, T, mrg in [(m_, t_, 0) for m_ in (1, 2) for t_ in (1, 2, 4, 8)] + ([(1, t_, 1) for t_ in (1, 2, 4, 8, 16)] if cin % 32 == 4 else []):      # mrg: remainder plane on the last group's pass (bit 12)
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, mf | 8 << 8 | mrg << 12 | T << 16 | 1 << 25))
         try:
             us = measure(plan, op, bufs, 0)
         except M._lib.MfviError as e:
             print("fwd bf16x6 mf=%d: not served (%s)" % (mf, e)); continue
         if lib.mfvi_plan_last_kernel(plan.handle, op, 0) != 3:
             print("%d->%d @%d fwd        bf16x6 mf=%d T=%d: not served (fell back to kernel family %d)" % (cin, cout, hw, mf, T, lib.mfvi_plan_last_kernel(plan.handle, op, 0)), flush=True); continue
-        print("%d->%d @%d fwd        bf16x6 mf=%d sr=8 T=%d: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak, %.3f of 2.5 PF / 6)" % (cin, cout, hw, mf, T, us, tf(us), tf(us) / 157.3, tf(us) / (2500.0 / 6)), flush=True)
+        print("%d->%d @%d fwd        bf16x6 mf=%d%s sr=8 T=%d: %7.1f us %5.1f TF (%.3f of the fp32 MFMA peak, %.3f of 2.5 PF / 6)" % (cin, cout, hw, mf, " merged" if mrg else "", T, us, tf(us), tf(us) / 157.3, tf(us) / (2500.0 / 6)), flush=True)
     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, op, 0, basef))

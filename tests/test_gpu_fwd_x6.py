@@ -32,8 +32,9 @@ def test_x6_forward_against_oracle(M, case):
     d_mu, d_rho, d_x = dev(mu), dev(rho), dev(x)
     bn = torch.zeros(1, device="cuda")
     lib = M._lib.lib()
-    for mf, T in ((1, 1), (2, 1), (1, 2), (2, 3)):
-        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, mf | 8 << 8 | T << 16 | X6))
+    # (third field: bit 12 of the tiling = the remainder plane rides on the last group's pass — one output fragment per wave, Cin = 32 n + 4)
+    for mf, T, mrg in ((1, 1, 0), (2, 1, 0), (1, 2, 0), (2, 3, 0)) + (((1, 1, 1), (1, 3, 1)) if cin % 32 == 4 else ()):
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, mf | 8 << 8 | mrg << 12 | T << 16 | X6))
         yh = host(plan.forward(d_mu, d_rho, bn, d_x, seed, step, k0, n))
         assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) == 3, "the bf16x6 kernel did not run"
         for i in range(n):
@@ -46,7 +47,7 @@ def test_x6_forward_against_oracle(M, case):
     assert relerr(host(y0)[0], O.conv_fwd(x, mu[:nw].reshape(cout, cin, 3, 3), mu[nw:], 1)) < 2e-6
 
 
-@pytest.mark.parametrize("shape", [(36, 16, 16, 64), (68, 32, 8, 128), (32, 32, 8, 64), (132, 64, 8, 64), (100, 24, 16, 64)])
+@pytest.mark.parametrize("shape", [(36, 16, 16, 64), (36, 16, 24, 128), (68, 32, 8, 128), (32, 32, 8, 64), (132, 64, 8, 64), (100, 24, 16, 64)])
 def test_x6_forward_against_fp32_mfma(M, shape):
     """conv -> BN+act -> 3x3 (under test) -> BN+act -> conv: deferred BN + LeakyReLU on load, reflected rows / columns in every position,
     the remainder plane, BN statistics of the output (they feed the next layer and the whole backward pass)."""
@@ -58,8 +59,8 @@ def test_x6_forward_against_fp32_mfma(M, shape):
     lib = M._lib.lib()
     M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, enc(1, 8, 1)))
     ref = _run_plan(plan, P, seed, n, z, dout)
-    for mf, T in ((1, 1), (2, 1), (1, 2), (2, 4)):
-        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, mf | 8 << 8 | T << 16 | X6))
+    for mf, T, mrg in ((1, 1, 0), (2, 1, 0), (1, 2, 0), (2, 4, 0)) + (((1, 1, 1), (1, 2, 1), (1, 8, 1)) if cin % 32 == 4 else ()):
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, mf | 8 << 8 | mrg << 12 | T << 16 | X6))
         got = _run_plan(plan, P, seed, n, z, dout)
         assert lib.mfvi_plan_last_kernel(plan.handle, 1, 0) == 3, "the bf16x6 kernel did not run"
         assert relerr(got[0], ref[0]) < 2e-6, ("out", mf)
