@@ -197,9 +197,15 @@ int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
 /* Kernel family that served conv op `op` in its last forward (which 0) / backward-data (1) / backward-weight (2) launch: 0 = generic fp32
  * VALU kernels (also: a tiling the shape does not admit falls back to them), 1 = fp32 MFMA kernels, 2 = row-phase fp32 MFMA kernels
  * (3x3 stride 1, maps a multiple of 64 wide or exactly 32 / 16 wide), 3 = bf16x6 kernels (fp32 operands as three bf16 pieces on the bf16
- * matrix instruction: forward tune bit 25 = mf | rows << 8 | strips per block << 16; backward-weight w = 11, input tiles field = output
- * fragments per block), 4 = small-map forward / backward-data (3x3 stride 1 on 8- / 16-wide maps, <= 144 reduction channels: tune = 1 | 1 << 26; the whole
- * reduction of a block in LDS, one stage).  -1: bad arguments.  Tests use it to prove that the kernel under test is the one that ran. */
+ * matrix instruction: forward tune bit 25 = mf | rows << 8 | strips per block << 16, bit 12 = the 4-channel remainder plane rides on the
+ * last 32-channel group's pass (mf = 1, Cin = 32 n + 4); backward-data with the fold tune bit 25 = strips per block | rows per strip << 8
+ * (8 / 4 / 2 for 16 / 32 / 64 output channels), bit 16 = the strip-resident form for 32 (+ 4) -> 16 layers (conv_bwd_x6s.hip);
+ * backward-weight w = 11, input tiles field = output fragments per block), 4 = one-stage kernels with the block's whole reduction in LDS
+ * (tune = 1 | 1 << 26: 3x3 stride 1 on 8- / 16-wide maps with <= 144 reduction channels, conv_small.hip; 1x1 layers with 16 | Cin, Cout <= 128
+ * and 2 / 4 / 8 output fragments on maps of 64 n pixels, conv_1x1.hip), 5 (backward-data slot only) = no launch of its own: the gradient of a
+ * narrow 1x1 convolution (<= 8 output channels) wrt an input it shares with one other convolution is formed inside that tensor's fold
+ * (finalize_dx_vec1_kernel; MFVI_FUSE_SKIP_BWD=0 keeps the separate launch).  -1: bad arguments.  Tests use it to prove that the kernel
+ * under test is the one that ran. */
 int mfvi_plan_last_kernel(const mfvi_plan* plan, int op, int which);
 
 /* ---- losses -------------------------------------------------------------------------------------------- */
