@@ -601,11 +601,12 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradFinEntry* 
 // eps_k from the counter RNG (domain EPS, stream 2*layer [+1 bias], sample k0+k, step); weights use the hardware-exp
 // softplus_fast, biases the libm-grade softplus_f — the same split the conv kernels used when they sampled in place.
 // grid: x = blocks of SAMPLE_QUADS quads over all layers of the table, y = sample.
+constexpr int SAMPLE_KPT = 4;      // samples per thread of the draw
 template <bool BF16>
 __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* __restrict__ table, int n_entries,
                                                              const void* __restrict__ mu_v, const void* __restrict__ rho_v,
                                                              RngKey key, float* __restrict__ wsamp, long long wstride, int sample,
-                                                             double* __restrict__ zero, long long n_zero)
+                                                             double* __restrict__ zero, long long n_zero, int n_k)
 {
     key = key_now(key);
     // the pass's statistics buffers, cleared by the draw's own threads (plan.hip, mfvi_forward)
@@ -614,35 +615,42 @@ __global__ __launch_bounds__(256) void sample_weights_kernel(const SampleEntry* 
     const PT* __restrict__ mu = static_cast<const PT*>(mu_v); const PT* __restrict__ rho = static_cast<const PT*>(rho_v);
     __shared__ int s_first[TABLE_LDS];
     const SampleEntry e = table[find_entry(table, n_entries, (int)blockIdx.x, s_first)];
-    const int k = blockIdx.y;
+    // a thread draws its quad for SAMPLE_KPT consecutive samples (grid y = groups of samples): mu, rho and softplus(rho) — a fifth of the
+    // work per (quad, sample) — once per thread instead of once per sample (round 4; the draws themselves are per (sample, quad) as before)
+    const int k0 = (int)blockIdx.y * SAMPLE_KPT, k1 = min(k0 + SAMPLE_KPT, n_k);
     const int item = ((int)blockIdx.x - e.first_block) * SAMPLE_QUADS + (int)threadIdx.x;
     const int nq_w = e.n_w >> 2, nq_b = (e.n_b + 3) >> 2;
     if (item >= nq_w + nq_b) return;
-    RngKey kw = key; kw.sample += (uint32_t)k;
-    float* __restrict__ o = wsamp + (long long)k * wstride;
-    float z[4] = {0.f, 0.f, 0.f, 0.f};
     if (item < nq_w) {
-        kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id);
-        if (sample) spec_normal4(kw, (uint32_t)item, z);
         const long long j = e.w_off + 4LL * item;
         float4 m, r;
         if constexpr (BF16) { m = bf16x4_to_f32(mu + j); r = bf16x4_to_f32(rho + j); }
         else { m = *reinterpret_cast<const float4*>(mu + j); r = *reinterpret_cast<const float4*>(rho + j); }
-        float4 w = m;
-        if (sample) {
-            w.x = __builtin_fmaf(softplus_fast(r.x), z[0], m.x); w.y = __builtin_fmaf(softplus_fast(r.y), z[1], m.y);
-            w.z = __builtin_fmaf(softplus_fast(r.z), z[2], m.z); w.w = __builtin_fmaf(softplus_fast(r.w), z[3], m.w);
+        float sp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sample) { sp[0] = softplus_fast(r.x); sp[1] = softplus_fast(r.y); sp[2] = softplus_fast(r.z); sp[3] = softplus_fast(r.w); }
+        for (int k = k0; k < k1; ++k) {
+            RngKey kw = key; kw.sample += (uint32_t)k;
+            kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id);
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (sample) spec_normal4(kw, (uint32_t)item, z);
+            float4 w = m;
+            if (sample) { w.x = __builtin_fmaf(sp[0], z[0], m.x); w.y = __builtin_fmaf(sp[1], z[1], m.y); w.z = __builtin_fmaf(sp[2], z[2], m.z); w.w = __builtin_fmaf(sp[3], z[3], m.w); }
+            *reinterpret_cast<float4*>(wsamp + (long long)k * wstride + j) = w;
         }
-        *reinterpret_cast<float4*>(o + j) = w;
     } else {
         const int q = item - nq_w;
-        kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id + 1);
-        if (sample) spec_normal4(kw, (uint32_t)q, z);
-        for (int l = 0; l < 4 && 4 * q + l < e.n_b; ++l) {
-            const long long j = e.b_off + 4 * q + l;
-            float mj, rj;
-            if constexpr (BF16) { mj = bf16_to_f32(mu[j]); rj = bf16_to_f32(rho[j]); } else { mj = mu[j]; rj = rho[j]; }
-            o[j] = sample ? mj + softplus_f(rj) * z[l] : mj;
+        for (int k = k0; k < k1; ++k) {
+            RngKey kw = key; kw.sample += (uint32_t)k;
+            kw.stream = ((uint32_t)DOMAIN_EPS << 24) | (uint32_t)(2 * e.layer_id + 1);
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (sample) spec_normal4(kw, (uint32_t)q, z);
+            float* __restrict__ o = wsamp + (long long)k * wstride;
+            for (int l = 0; l < 4 && 4 * q + l < e.n_b; ++l) {
+                const long long j = e.b_off + 4 * q + l;
+                float mj, rj;
+                if constexpr (BF16) { mj = bf16_to_f32(mu[j]); rj = bf16_to_f32(rho[j]); } else { mj = mu[j]; rj = rho[j]; }
+                o[j] = sample ? mj + softplus_f(rj) * z[l] : mj;
+            }
         }
     }
 }
@@ -714,8 +722,9 @@ int launch_sample_weights(const SampleEntry* table_dev, int n_entries, int n_blo
                           int n_samples, float* wsamp, long long wstride, hipStream_t st, int bf16, int sample, double* zero, long long n_zero)
 {
     if (n_entries < 1 || n_blocks < 1) { if (n_zero > 0) return (int)hipMemsetAsync(zero, 0, sizeof(double) * n_zero, st); return 0; }
-    if (bf16) hipLaunchKernelGGL(sample_weights_kernel<true>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample, zero, n_zero);
-    else hipLaunchKernelGGL(sample_weights_kernel<false>, dim3(n_blocks, n_samples), dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample, zero, n_zero);
+    const dim3 grid(n_blocks, (n_samples + SAMPLE_KPT - 1) / SAMPLE_KPT);
+    if (bf16) hipLaunchKernelGGL(sample_weights_kernel<true>, grid, dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample, zero, n_zero, n_samples);
+    else hipLaunchKernelGGL(sample_weights_kernel<false>, grid, dim3(256), 0, st, table_dev, n_entries, mu, rho, key, wsamp, wstride, sample, zero, n_zero, n_samples);
     return (int)hipGetLastError();
 }
 
