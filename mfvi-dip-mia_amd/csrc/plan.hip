@@ -1138,7 +1138,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
     const RngKey key = base_key(1, 0, 0);
     hipEvent_t ea, eb;
     if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) { set_error("autotune: hipEventCreate failed"); return -1; }
-    const int reps = 3;
+    const int reps = 6;
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         OpInfo& o = plan->ops[i];
         if (o.d.type != MFVI_OP_CONV) continue;
@@ -1224,7 +1224,7 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                 if (rc == -3) continue;
                 if (rc) { set_error("autotune: op %d launch failed: %s", (int)i, rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad arguments"); goto done; }
                 float ms = 1e30f;
-                for (int trial = 0; trial < 2 && !rc; ++trial) {      // best of two timings of `reps` launches: the choice must not flip on noise
+                for (int trial = 0; trial < 3 && !rc; ++trial) {      // best of three timings of `reps` launches: the choice must not flip on noise
                     (void)hipEventRecord(ea, st);
                     for (int r = 0; r < reps && !rc; ++r) rc = launch();
                     (void)hipEventRecord(eb, st);
