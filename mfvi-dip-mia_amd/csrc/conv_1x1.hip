@@ -220,7 +220,119 @@ int c1_launch(int mode, C1Args& A, int n_samples, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+// ---- streaming forward for the narrow 1x1 layers of the top scales (round 4): 16 -> 16 / 4 / 2 @256^2 ----
+// These launches are memory streams (67 MB in, 67 MB out for 16 -> 16 @256^2, K = 16) that the staged kernel runs at 2.9-3.7 TB/s: a tile goes
+// global -> registers -> LDS -> barrier -> matrix -> store, a few tiles in flight per CU.  Here nothing goes through LDS: a wave owns groups
+// of 64 consecutive pixels; lane (k = lane >> 4, n = lane & 15) loads the float4 x[4 s + k][p0 + 4 n ..] straight into the B operands of four
+// v_mfma_f32_16x16x4_f32 (deferred BN + LeakyReLU in the register), the A operand W[co = n][4 s + k] stays in registers, the results get
+// their bias and leave as float4 of consecutive pixels (256-byte channel segments both ways); UNR groups' loads are in flight at once.  BN statistics: per-lane partials, one
+// 16-lane DPP reduction at the end, LDS across the block's waves, one fp64 atomic per (block, channel, moment).
+constexpr int C1S_MAXNS = 16;      // reduction channels / 4
+
+__device__ __forceinline__ float c1s_row_sum16(float v) { return c1_row_sum16(v); }
+
+template <int NS, int UNR>
+__global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
+{
+    __shared__ ChanFwd s_ch[4 * C1S_MAXNS];
+    __shared__ float s_part[4][16][2];
+    const ConvGeom& g = A.g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int k = blockIdx.y;
+    const int HW = g.H * g.W, Cin = g.Cin, Cout = g.Cout;
+    const float* __restrict__ wk = A.w + (long long)k * A.wstride + g.w_off;
+    const float* __restrict__ xk = A.xin.data + (long long)k * A.xin.sstride;
+    float* __restrict__ yk = A.out.data + (long long)k * A.out.sstride;
+    for (int c = tid; c < Cin; c += 256) s_ch[c] = chan_fwd(A.xin, k, c);
+    // A operand: W[co = l15][ci = 4 s + l4]; bias of this lane's four output channels
+    float a[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = l15 < Cout ? wk[(long long)l15 * Cin + 4 * s + l4] : 0.f;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = (g.b_off >= 0 && 4 * l4 + r < Cout) ? wk[g.b_off - g.w_off + 4 * l4 + r] : 0.f;
+    __syncthreads();
+    float ksc[NS], ksh[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { const ChanFwd f = s_ch[4 * s + l4]; ksc[s] = f.scale; ksh[s] = __builtin_fmaf(-f.mean, f.scale, f.beta); }
+    const bool lrelu = (A.xin.act & 1) != 0; const float slope = A.xin.slope;
+    // a group = 64 consecutive pixels: lane (k, n) loads the float4 x[4 s + k][p0 + 4 n .. 4 n + 3] (16 lanes = 256 contiguous bytes of a channel),
+    // component j of it is the B operand of the j-th of four matrix instructions, whose result register r is y[4 k + r][p0 + 4 n + j]:
+    // the four results of a channel are again a float4 of consecutive pixels
+    const int n_groups = HW >> 6;
+    const int gstride = gridDim.x * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_stats = A.out.stats != nullptr;
+    for (int g0 = blockIdx.x * 4 + wv; g0 < n_groups; g0 += gstride * UNR) {
+        float4 xv[UNR][NS];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int gi = min(g0 + u * gstride, n_groups - 1);      // (clamped: every load unconditional; groups past the end are not stored)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) xv[u][s] = *reinterpret_cast<const float4*>(xk + (long long)(4 * s + l4) * HW + 64 * gi + 4 * l15);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int gi = g0 + u * gstride;
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float v[4] = {xv[u][s].x, xv[u][s].y, xv[u][s].z, xv[u][s].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = __builtin_fmaf(v[j], ksc[s], ksh[s]);
+                    if (lrelu) v[j] = __builtin_fmaxf(v[j], v[j] * slope);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], v[j], acc[j], 0, 0, 0);
+                }
+            }
+            if (gi >= n_groups) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y0 = acc[0][r] + bias[r], y1 = acc[1][r] + bias[r], y2 = acc[2][r] + bias[r], y3 = acc[3][r] + bias[r];
+                if (4 * l4 + r < Cout) *reinterpret_cast<float4*>(yk + (long long)(4 * l4 + r) * HW + 64 * gi + 4 * l15) = make_float4(y0, y1, y2, y3);
+                s1[r] += (y0 + y1) + (y2 + y3); s2[r] = __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, __builtin_fmaf(y2, y2, __builtin_fmaf(y3, y3, s2[r]))));
+            }
+        }
+    }
+    if (do_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t1 = c1s_row_sum16(s1[r]), t2 = c1s_row_sum16(s2[r]);
+            if (l15 == 15) { s_part[wv][4 * l4 + r][0] = t1; s_part[wv][4 * l4 + r][1] = t2; }
+        }
+        __syncthreads();
+        if (tid < 2 * Cout) {
+            const int c = tid >> 1, which = tid & 1;
+            const float v = (s_part[0][c][which] + s_part[1][c][which]) + (s_part[2][c][which] + s_part[3][c][which]);
+            atomicAdd(A.out.stats + ((long long)k * Cout + c) * 2 + which, (double)v);
+        }
+    }
+}
+
 }  // namespace
+
+// streaming forward of a narrow 1x1 layer (tune bit 28): Cin a multiple of 4 up to 64, Cout <= 16, H*W a multiple of 16.  -2: shape not served
+int launch_conv1_fwd_stream(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st)
+{
+    if (g.ks != 1 || g.stride != 1 || (g.Cin & 3) || g.Cin > 4 * C1S_MAXNS || g.Cout > 16 || (((long long)g.H * g.W) & 63) || (in.act & MFVI_ACT_SQUARE)) return -2;
+    if ((in.sstride & 3) || (out.sstride & 3) || (((uintptr_t)in.data | (uintptr_t)out.data) & 15)) return -2;      // float4 rows
+    if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 31)) return -2;
+    C1Args A{};
+    A.xin = in; A.g = g; A.w = w; A.wstride = wstride; A.out = out;
+    const int n_groups = (g.H * g.W) >> 6;
+    const int ns = g.Cin >> 2;
+    if (ns != 1 && ns != 2 && ns != 3 && ns != 4 && ns != 8 && ns != 16) return -2;      // (instantiated reduction depths: 4 ... 16, 32, 64 channels)
+    // blocks: enough to fill the chip four times over at most, each wave with at least one full unrolled batch where the map allows
+    const int nb = max(1, min((n_groups + 7) / 8, (256 * 8 + n_samples - 1) / n_samples));
+    mfvi_tl_family = 6;
+    const dim3 grid(nb, n_samples);
+#define C1S_GO(NS_, U_) mfvi_launch((conv1_stream_kernel<NS_, U_>), grid, dim3(256), 0, st, A)
+    if (ns <= 4) { if (ns == 4) C1S_GO(4, 2); else if (ns == 3) C1S_GO(3, 2); else if (ns == 2) C1S_GO(2, 4); else C1S_GO(1, 4); }
+    else if (ns == 8) C1S_GO(8, 1);
+    else C1S_GO(16, 1);
+#undef C1S_GO
+    return (int)hipGetLastError();
+}
 
 // -2: shape not served
 int launch_conv1_fwd_small(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st)

@@ -1183,6 +1183,10 @@ int launch_conv_fwd_mfma(const TView& in, const ConvGeom& g, const float* w, lon
     if ((g.W & 3) || g.W < 4 || (in.sstride & 3) || ((uintptr_t)in.data & 15)) return -2;
     {   // row-phase kernels (conv_rp.hip): an explicit tiling of the plan / autotuner, or the default for the shapes they serve
         int tn = g.tune[0] ? g.tune[0] : (env_tune() ? 0 : rp_default_tune(g, 0, n_samples));
+        if (tn & MFVI_TUNE_ST) {      // streaming forward of a narrow 1x1 layer (conv_1x1.hip): only as an explicit tiling of the plan / autotuner
+            const int rc = launch_conv1_fwd_stream(in, g, w, wstride, out, n_samples, st);
+            return rc == -2 ? -3 : rc;
+        }
         if (tn & MFVI_TUNE_SM) {      // small-map forward (conv_small.hip): only as an explicit tiling of the plan / autotuner
             const int rc = g.ks == 1 ? launch_conv1_fwd_small(in, g, w, wstride, out, n_samples, st) : launch_conv_fwd_small(in, g, w, wstride, out, n_samples, st);
             return rc == -2 ? -3 : rc;

@@ -142,3 +142,63 @@ def test_conv1x1_small_net_against_oracle(M):
     assert relerr(host(dmu), r_dmu) < 2e-4
     assert relerr(host(drho), r_drho) < 2e-4
     assert relerr(host(dbn), r_dbn) < 2e-4
+
+
+ST = 1 | 1 << 28
+
+
+# streaming forward of the narrow 1x1 layers (conv1_stream_kernel, tune bit 28): reduction depths 4 ... 16, 32, 64; 16 / 4 / 2 / 3 output channels;
+# maps from one 64-pixel group per block to several unrolled batches with a ragged tail
+ST_CASES = [(16, 16, 32, 64), (16, 4, 64, 64), (16, 2, 16, 48), (4, 16, 8, 8), (8, 3, 8, 24), (12, 16, 16, 16), (32, 4, 32, 32), (64, 4, 16, 16)]
+
+
+@pytest.mark.parametrize("case", ST_CASES)
+def test_conv1x1_streaming_forward_against_oracle(M, case):
+    cin, cout, H, W = case
+    seed, step, k0, n = 3300 + cin + cout + H, 3, 2, 3
+    P = M.Program()
+    zin = P.tensor(cin, H, W); out = P.tensor(cout, H, W); P.conv(zin, out, 1, 1)
+    plan = P.compile(zin, out, max_samples=n)
+    nw = cout * cin
+    mu = 0.1 * O.normal_fill(seed, 2, 0, 0, 0, nw + cout); rho = -3 + 0.1 * O.normal_fill(seed, 2, 1, 0, 0, nw + cout)
+    x = O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W)
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, ST))
+    y = plan.forward(dev(mu), dev(rho), torch.zeros(1, device="cuda"), dev(x), seed, step, k0, n)
+    assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) == 6
+    yh = host(y)
+    for i in range(n):
+        ew = O.eps(seed, step, k0 + i, 0, 0, nw); eb = O.eps(seed, step, k0 + i, 0, 1, cout)
+        w = O.reparam(mu[:nw], rho[:nw], ew).reshape(cout, cin, 1, 1); b = O.reparam(mu[nw:], rho[nw:], eb)
+        assert relerr(yh[i], O.conv_fwd(x, w, b, 1)) < 2e-6, ("fwd", i)
+
+
+@pytest.mark.parametrize("case", [(16, 16, 32, 64), (16, 4, 16, 48), (32, 4, 16, 16)])
+def test_conv1x1_streaming_forward_inside_a_plan(M, case):
+    """z -> 3x3 -> BN+act -> 1x1 (under test, streaming) -> BN+act -> 1x1 -> out: deferred BN + LeakyReLU in the register, the output's BN statistics
+    (they feed the next layer and the whole backward pass): every gradient against the staged kernel."""
+    cin, cout, H, W = case
+    n, seed = 2, 103
+    P, plan, zin, out = _plan_1x1(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, 8 * H * W).reshape(8, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    ref = _run(plan, P, seed, n, z, dout)
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 0, ST))
+    got = _run(plan, P, seed, n, z, dout)
+    assert lib.mfvi_plan_last_kernel(plan.handle, 1, 0) == 6, "the streaming kernel did not run"
+    assert relerr(got[0], ref[0]) < 3e-6
+    for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dbn", "dz")):
+        assert relerr(a, b) < 2e-5, name
+
+
+def test_conv1x1_streaming_unserved_shapes_fall_back(M):
+    lib = M._lib.lib()
+    for cin, cout, H, W in ((20, 4, 8, 8), (16, 32, 8, 8), (16, 4, 3, 5)):
+        P = M.Program()
+        zin = P.tensor(cin, H, W); out = P.tensor(cout, H, W); P.conv(zin, out, 1, 1)
+        plan = P.compile(zin, out, max_samples=1)
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 0, 0, ST))
+        z = torch.zeros
+        plan.forward(z(P.n_vi, device="cuda"), z(P.n_vi, device="cuda"), z(1, device="cuda"), z(cin * H * W, device="cuda"), 1, 0, 0, 1)
+        assert lib.mfvi_plan_last_kernel(plan.handle, 0, 0) == 0
