@@ -59,7 +59,7 @@ def dropin_curve(M, size, steps, every, seed, flat=False):
     net = M.get_net(16, 'skip', 'reflection', 'bilinear', n_channels=2, skip_n33d=[16, 32, 64, 128, 128], skip_n33u=[16, 32, 64, 128, 128],
                     skip_n11=4, num_scales=5)
     net = M.MeanFieldVI(net, prior={'mu': 0.0, 'sigma': float(np.sqrt(DEN["temp"]) * DEN["sigma"])}, replace_layers='all', device=dev,
-                        reparam='', seed=seed, flat_parameters=flat)
+                        reparam='', seed=seed, flat_parameters=flat, autotune=False)      # (heuristic tilings as in engine_curve: the autotuner's per-box choices change summation orders, and this fit amplifies them)
     onet = O.make_net(size, size)
     mu, rho, bnp = O.init_params(onet, seed)
     with torch.no_grad():
