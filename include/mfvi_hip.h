@@ -205,7 +205,7 @@ int mfvi_plan_set_tune(mfvi_plan* plan, int op, int which, int tune);
  * and 2 / 4 / 8 output fragments on maps of 64 n pixels, conv_1x1.hip), 5 (backward-data slot only) = no launch of its own: the gradient of a
  * narrow 1x1 convolution (<= 8 output channels) wrt an input it shares with one other convolution is formed inside that tensor's fold
  * (finalize_dx_vec1_kernel; MFVI_FUSE_SKIP_BWD=0 keeps the separate launch), 6 (forward slot only) = streaming forward of a narrow 1x1
- * layer (tune = 1 | 1 << 28: Cin in {4 ... 16, 32, 64}, at most 16 output channels, maps of 64 n pixels; conv_1x1.hip).  -1: bad arguments.  Tests use it to prove that the kernel
+ * layer (tune = 1 | 1 << 28: Cin in {4 ... 16, 32, 64}, at most 16 output channels (32 for 16 or 32 input channels), maps of 64 n pixels; conv_1x1.hip).  -1: bad arguments.  Tests use it to prove that the kernel
  * under test is the one that ran. */
 int mfvi_plan_last_kernel(const mfvi_plan* plan, int op, int which);
 

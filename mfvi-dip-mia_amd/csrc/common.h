@@ -405,7 +405,7 @@ int rp_default_tune(const ConvGeom& g, int mode, int n_samples);      // 0: not 
 #define MFVI_INKERNEL_MAX_W 2560
 int launch_conv_fwd_small(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);
 int launch_conv_bwd_data_small(const GView& gy, const ConvGeom& g, const float* w, long long wstride, int n_samples, hipStream_t st, const FoldFuse& fuse);
-// Streaming forward of the narrow 1x1 layers (conv_1x1.hip, conv1_stream_kernel): Cin in {4, 8, 12, 16, 32, 64}, Cout <= 16, H*W a multiple of 64;
+// Streaming forward of the narrow 1x1 layers (conv_1x1.hip, conv1_stream_kernel): Cin in {4, 8, 12, 16, 32, 64}, Cout <= 16 (<= 32 for Cin 16 / 32), H*W a multiple of 64;
 // nothing through LDS, the pixel operand straight from global memory into the matrix instruction.  Tune bit 28; -2: shape not served
 #define MFVI_TUNE_ST (1 << 28)
 int launch_conv1_fwd_stream(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st);

@@ -231,11 +231,11 @@ constexpr int C1S_MAXNS = 16;      // reduction channels / 4
 
 __device__ __forceinline__ float c1s_row_sum16(float v) { return c1_row_sum16(v); }
 
-template <int NS, int UNR>
+template <int NS, int UNR, int NF>      // reduction channels / 4, groups in flight per wave, output fragments of 16 channels (1 or 2)
 __global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
 {
     __shared__ ChanFwd s_ch[4 * C1S_MAXNS];
-    __shared__ float s_part[4][16][2];
+    __shared__ float s_part[4][16 * NF][2];
     const ConvGeom& g = A.g;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int k = blockIdx.y;
@@ -244,13 +244,15 @@ __global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
     const float* __restrict__ xk = A.xin.data + (long long)k * A.xin.sstride;
     float* __restrict__ yk = A.out.data + (long long)k * A.out.sstride;
     for (int c = tid; c < Cin; c += 256) s_ch[c] = chan_fwd(A.xin, k, c);
-    // A operand: W[co = l15][ci = 4 s + l4]; bias of this lane's four output channels
-    float a[NS];
+    // A operand: W[co = 16 f + l15][ci = 4 s + l4]; bias of this lane's four output channels per fragment
+    float a[NF][NS], bias[NF][4];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) a[s] = l15 < Cout ? wk[(long long)l15 * Cin + 4 * s + l4] : 0.f;
-    float bias[4];
+    for (int f = 0; f < NF; ++f) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = (g.b_off >= 0 && 4 * l4 + r < Cout) ? wk[g.b_off - g.w_off + 4 * l4 + r] : 0.f;
+        for (int s = 0; s < NS; ++s) a[f][s] = 16 * f + l15 < Cout ? wk[(long long)(16 * f + l15) * Cin + 4 * s + l4] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[f][r] = (g.b_off >= 0 && 16 * f + 4 * l4 + r < Cout) ? wk[g.b_off - g.w_off + 16 * f + 4 * l4 + r] : 0.f;
+    }
     __syncthreads();
     float ksc[NS], ksh[NS];
 #pragma unroll
@@ -261,7 +263,11 @@ __global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
     // the four results of a channel are again a float4 of consecutive pixels
     const int n_groups = HW >> 6;
     const int gstride = gridDim.x * 4;
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1[NF][4], s2[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
     const bool do_stats = A.out.stats != nullptr;
     for (int g0 = blockIdx.x * 4 + wv; g0 < n_groups; g0 += gstride * UNR) {
         float4 xv[UNR][NS];
@@ -274,7 +280,11 @@ __global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int gi = g0 + u * gstride;
-            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[NF][4];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 float v[4] = {xv[u][s].x, xv[u][s].y, xv[u][s].z, xv[u][s].w};
@@ -282,24 +292,29 @@ __global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
                 for (int j = 0; j < 4; ++j) {
                     v[j] = __builtin_fmaf(v[j], ksc[s], ksh[s]);
                     if (lrelu) v[j] = __builtin_fmaxf(v[j], v[j] * slope);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], v[j], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][s], v[j], acc[f][j], 0, 0, 0);
                 }
             }
             if (gi >= n_groups) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y0 = acc[0][r] + bias[r], y1 = acc[1][r] + bias[r], y2 = acc[2][r] + bias[r], y3 = acc[3][r] + bias[r];
-                if (4 * l4 + r < Cout) *reinterpret_cast<float4*>(yk + (long long)(4 * l4 + r) * HW + 64 * gi + 4 * l15) = make_float4(y0, y1, y2, y3);
-                s1[r] += (y0 + y1) + (y2 + y3); s2[r] = __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, __builtin_fmaf(y2, y2, __builtin_fmaf(y3, y3, s2[r]))));
-            }
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = acc[f][0][r] + bias[f][r], y1 = acc[f][1][r] + bias[f][r], y2 = acc[f][2][r] + bias[f][r], y3 = acc[f][3][r] + bias[f][r];
+                    if (16 * f + 4 * l4 + r < Cout) *reinterpret_cast<float4*>(yk + (long long)(16 * f + 4 * l4 + r) * HW + 64 * gi + 4 * l15) = make_float4(y0, y1, y2, y3);
+                    s1[f][r] += (y0 + y1) + (y2 + y3); s2[f][r] = __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, __builtin_fmaf(y2, y2, __builtin_fmaf(y3, y3, s2[f][r]))));
+                }
         }
     }
     if (do_stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float t1 = c1s_row_sum16(s1[r]), t2 = c1s_row_sum16(s2[r]);
-            if (l15 == 15) { s_part[wv][4 * l4 + r][0] = t1; s_part[wv][4 * l4 + r][1] = t2; }
-        }
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t1 = c1s_row_sum16(s1[f][r]), t2 = c1s_row_sum16(s2[f][r]);
+                if (l15 == 15) { s_part[wv][16 * f + 4 * l4 + r][0] = t1; s_part[wv][16 * f + 4 * l4 + r][1] = t2; }
+            }
         __syncthreads();
         if (tid < 2 * Cout) {
             const int c = tid >> 1, which = tid & 1;
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(256) void conv1_stream_kernel(C1Args A)
 // streaming forward of a narrow 1x1 layer (tune bit 28): Cin a multiple of 4 up to 64, Cout <= 16, H*W a multiple of 16.  -2: shape not served
 int launch_conv1_fwd_stream(const TView& in, const ConvGeom& g, const float* w, long long wstride, OutDesc out, int n_samples, hipStream_t st)
 {
-    if (g.ks != 1 || g.stride != 1 || (g.Cin & 3) || g.Cin > 4 * C1S_MAXNS || g.Cout > 16 || (((long long)g.H * g.W) & 63) || (in.act & MFVI_ACT_SQUARE)) return -2;
+    if (g.ks != 1 || g.stride != 1 || (g.Cin & 3) || g.Cin > 4 * C1S_MAXNS || g.Cout > 32 || (((long long)g.H * g.W) & 63) || (in.act & MFVI_ACT_SQUARE)) return -2;
     if ((in.sstride & 3) || (out.sstride & 3) || (((uintptr_t)in.data | (uintptr_t)out.data) & 15)) return -2;      // float4 rows
     if ((long long)max(g.Cin, g.Cout) * g.H * g.W >= (1LL << 31)) return -2;
     C1Args A{};
@@ -326,10 +341,13 @@ int launch_conv1_fwd_stream(const TView& in, const ConvGeom& g, const float* w, 
     const int nb = max(1, min((n_groups + 7) / 8, (256 * 8 + n_samples - 1) / n_samples));
     mfvi_tl_family = 6;
     const dim3 grid(nb, n_samples);
-#define C1S_GO(NS_, U_) mfvi_launch((conv1_stream_kernel<NS_, U_>), grid, dim3(256), 0, st, A)
-    if (ns <= 4) { if (ns == 4) C1S_GO(4, 2); else if (ns == 3) C1S_GO(3, 2); else if (ns == 2) C1S_GO(2, 4); else C1S_GO(1, 4); }
-    else if (ns == 8) C1S_GO(8, 1);
-    else C1S_GO(16, 1);
+#define C1S_GO(NS_, U_, NF_) mfvi_launch((conv1_stream_kernel<NS_, U_, NF_>), grid, dim3(256), 0, st, A)
+    if (g.Cout > 16) {      // two output fragments: the 16 / 32 -> 32 layers
+        if (ns == 4) C1S_GO(4, 2, 2); else if (ns == 8) C1S_GO(8, 1, 2); else return -2;
+    }
+    else if (ns <= 4) { if (ns == 4) C1S_GO(4, 2, 1); else if (ns == 3) C1S_GO(3, 2, 1); else if (ns == 2) C1S_GO(2, 4, 1); else C1S_GO(1, 4, 1); }
+    else if (ns == 8) C1S_GO(8, 1, 1);
+    else C1S_GO(16, 1, 1);
 #undef C1S_GO
     return (int)hipGetLastError();
 }

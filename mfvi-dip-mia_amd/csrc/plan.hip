@@ -1199,8 +1199,8 @@ int mfvi_plan_autotune(mfvi_plan* plan, const void* mu, const void* rho, const f
                         cands.push_back(mf | 1 << 8 | rem << 12 | ks << 13 | 1 << 16 | MFVI_TUNE_RP);
                 // small-map forward (conv_small.hip): one stage, the block's whole reduction in LDS
                 if (which <= 1 && o.g.ks == 3 && o.g.stride == 1 && o.g.W <= 16) cands.push_back(1 | MFVI_TUNE_SM);
-                // streaming forward of the narrow 1x1 layers (conv_1x1.hip, conv1_stream_kernel): at most 16 output channels
-                if (which == 0 && o.g.ks == 1 && o.g.stride == 1 && o.g.Cout <= 16 && (o.g.Cin & 3) == 0 && o.g.Cin <= 64 && (((long long)o.g.H * o.g.W) & 63) == 0)
+                // streaming forward of the narrow 1x1 layers (conv_1x1.hip, conv1_stream_kernel): at most 32 output channels
+                if (which == 0 && o.g.ks == 1 && o.g.stride == 1 && o.g.Cout <= 32 && (o.g.Cin & 3) == 0 && o.g.Cin <= 64 && (((long long)o.g.H * o.g.W) & 63) == 0)
                     cands.push_back(1 | MFVI_TUNE_ST);
                 // one-stage 1x1 kernel (conv_1x1.hip): the `up` 1x1 layers of 32 ... 128 channels; same tune bit
                 if (which <= 1 && o.g.ks == 1 && o.g.stride == 1 && (o.g.Cin & 15) == 0 && (o.g.Cout & 15) == 0 && o.g.Cin <= 128 && o.g.Cout <= 128

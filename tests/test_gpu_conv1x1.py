@@ -149,7 +149,7 @@ ST = 1 | 1 << 28
 
 # streaming forward of the narrow 1x1 layers (conv1_stream_kernel, tune bit 28): reduction depths 4 ... 16, 32, 64; 16 / 4 / 2 / 3 output channels;
 # maps from one 64-pixel group per block to several unrolled batches with a ragged tail
-ST_CASES = [(16, 16, 32, 64), (16, 4, 64, 64), (16, 2, 16, 48), (4, 16, 8, 8), (8, 3, 8, 24), (12, 16, 16, 16), (32, 4, 32, 32), (64, 4, 16, 16)]
+ST_CASES = [(16, 16, 32, 64), (16, 4, 64, 64), (16, 2, 16, 48), (4, 16, 8, 8), (8, 3, 8, 24), (12, 16, 16, 16), (32, 4, 32, 32), (64, 4, 16, 16), (32, 32, 16, 32), (16, 24, 8, 8)]      # the last two: two output fragments
 
 
 @pytest.mark.parametrize("case", ST_CASES)
@@ -173,7 +173,7 @@ def test_conv1x1_streaming_forward_against_oracle(M, case):
         assert relerr(yh[i], O.conv_fwd(x, w, b, 1)) < 2e-6, ("fwd", i)
 
 
-@pytest.mark.parametrize("case", [(16, 16, 32, 64), (16, 4, 16, 48), (32, 4, 16, 16)])
+@pytest.mark.parametrize("case", [(16, 16, 32, 64), (16, 4, 16, 48), (32, 4, 16, 16), (32, 32, 16, 16)])
 def test_conv1x1_streaming_forward_inside_a_plan(M, case):
     """z -> 3x3 -> BN+act -> 1x1 (under test, streaming) -> BN+act -> 1x1 -> out: deferred BN + LeakyReLU in the register, the output's BN statistics
     (they feed the next layer and the whole backward pass): every gradient against the staged kernel."""
@@ -194,7 +194,7 @@ def test_conv1x1_streaming_forward_inside_a_plan(M, case):
 
 def test_conv1x1_streaming_unserved_shapes_fall_back(M):
     lib = M._lib.lib()
-    for cin, cout, H, W in ((20, 4, 8, 8), (16, 32, 8, 8), (16, 4, 3, 5)):
+    for cin, cout, H, W in ((20, 4, 8, 8), (16, 48, 8, 8), (64, 32, 8, 8), (16, 4, 3, 5)):
         P = M.Program()
         zin = P.tensor(cin, H, W); out = P.tensor(cout, H, W); P.conv(zin, out, 1, 1)
         plan = P.compile(zin, out, max_samples=1)
