@@ -41,6 +41,12 @@
  *      MFVI_SIDE_PRIO=0        side stream at default priority (default: lowest)
  *      MFVI_FWD_FORK=n         forward pass: skip-branch 1x1 convolutions on maps of up to n pixels run on the side stream (default 16384, 0 = off)
  *      MFVI_FORK_ON_PACKET=0   fork / join events as separate hipEventRecord packets instead of riding on kernel dispatch packets
+ *      MFVI_FUSE_SKIP_BWD=0    the narrow 1x1 skip convolutions keep their own backward-data launch (default: formed inside the fold of the
+ *                              tensor they share with the scale's stride-2 convolution, kernel family 5)
+ *      MFVI_CONCAT_TILED=w     concat forward: LDS-tiled kernel for maps at least w wide (default 128; 0 = never)
+ *      MFVI_CONCAT_TPB=n       concat forward, tiled kernel: tiles per block (default 4)
+ *      MFVI_CONCAT_BWD_TILE=w  concat backward: force the 16 x 64 / 32 x 32 / 16 x 16 low-res tile (w = 64 / 32 / 16; default: by map width)
+ *      MFVI_INKERNEL_MAX_W     (compile-time, csrc/common.h) largest layer the autotuner tries on the in-kernel-eps generic kernels (tune bit 27)
  *      MFVI_DEBUG_FIN          print the gradient-reduction table to stderr
  */
 #ifndef MFVI_HIP_H
