@@ -88,6 +88,24 @@ def test_x6_strip_resident_form_against_fp32_tilings(M, shape, act):
             assert relerr(a, b) < 2e-5, (name, T)
 
 
+def test_x6_strip_resident_form_at_full_size(M):
+    """36 -> 16 at 256 x 512 (the band / strip counts of the BASELINE 256^2 and 512^2 configs): 32 strips of 8 rows, 8 bands, the block
+    counts the autotuner picks from (8 and 32 strips per block) against the fp32 tiling."""
+    cin, cout, H, W, n, seed = 36, 16, 256, 512, 2, 99
+    P, plan, zin, out = _conv_bn_plan(M, cin, cout, H, W, n)
+    z = dev(O.normal_fill(seed, 2, 2, 0, 0, cin * H * W).reshape(cin, H, W))
+    dout = dev(O.normal_fill(seed, 2, 3, 0, 0, n * 2 * H * W).reshape(n, 2, H, W))
+    lib = M._lib.lib()
+    M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, enc(1, 8, 1)))
+    ref = _run_plan(plan, P, seed, n, z, dout)
+    for T in (8, 32):
+        M._lib.check(lib.mfvi_plan_set_tune(plan.handle, 1, 1, x6_tune(cout, T) | 1 << 16))
+        got = _run_plan(plan, P, seed, n, z, dout)
+        assert lib.mfvi_plan_last_kernel(plan.handle, 1, 1) == 3
+        for a, b, name in zip(got[1:], ref[1:], ("dmu", "drho", "dz")):
+            assert relerr(a, b) < 2e-5, (name, T)
+
+
 def test_x6_strip_resident_form_refuses_other_shapes(M):
     """68 -> 32 with bit 16 set: the tiling is not valid for the shape (-3), the plan runs that launch on the generic kernel."""
     P, plan, zin, out = _conv_bn_plan(M, 68, 32, 8, 64, 1)
